@@ -1,0 +1,7 @@
+"""atsc_amd -- MI355X-native ATSC compression core (per-frame auto-compressor path).
+
+The product is libatsc_hip.so (hand-written gfx950 kernels behind the C ABI in
+include/atsc_hip.h).  This package only loads it and moves pointers around."""
+from . import capi  # noqa: F401
+from .capi import AUTO, CONSTANT, FFT, IDW, NOOP, POLYNOMIAL, RLE, AtscError  # noqa: F401
+from .engine import Context, DPlan, Plan, bro_open, bro_prefix, chunk_sizes, clean_data  # noqa: F401

@@ -1,0 +1,288 @@
+// atsc_decode.hip -- gfx950 kernels for CompressorFrame::decompress (atsc/src/frame/mod.rs:152-158
+// -> Compressor::decompress, atsc/src/compressor/mod.rs:109-119).
+//
+// One workgroup of W wavefronts per frame.  The payload header is walked by lane 0 (varint
+// fields are sequential by construction); the per-sample reconstruction is parallel:
+//   FFT         fft.rs:426-462      K-sparse Hermitian spectrum -> direct sum over the stored bins
+//                                   (f64 accumulation, f32 table twiddles), f32 result / L, round 5, clamp
+//   Polynomial  polynomial.rs:395-404,342-373  Catmull-Rom/linear pieces, exact f64 op order
+//   Constant    constant.rs:141-144 ; RLE rle.rs:204-236 ; Noop noop.rs:79-83
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "atsc_device.h"
+
+namespace atsc {
+
+struct Rd {
+    const uint8_t *p;
+    uint32_t len, pos;
+    bool bad;
+};
+DEVI uint32_t rd_u8(Rd &r)
+{
+    if (r.pos + 1 > r.len) { r.bad = true; return 0; }
+    return r.p[r.pos++];
+}
+DEVI uint64_t rd_le(Rd &r, uint32_t nb)
+{
+    if (r.pos + nb > r.len) { r.bad = true; return 0; }
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)r.p[r.pos + i] << (8 * i);
+    r.pos += nb;
+    return v;
+}
+DEVI uint64_t rd_varint(Rd &r)
+{
+    const uint32_t t = rd_u8(r);
+    if (t < 251) return t;
+    if (t == 251) return rd_le(r, 2);
+    if (t == 252) return rd_le(r, 4);
+    if (t == 253) return rd_le(r, 8);
+    r.bad = true;
+    return 0;
+}
+DEVI int64_t unzig(uint64_t u) { return (u & 1) ? (int64_t)~(u >> 1) : (int64_t)(u >> 1); }
+// value at a bitdepth: constant.rs:71-92, polynomial.rs:95-116, rle.rs:76-100
+DEVI double rd_value(Rd &r, uint32_t bd)
+{
+    if (bd == 3) return (double)rd_u8(r);
+    if (bd == 2) return (double)(int16_t)unzig(rd_varint(r));
+    if (bd == 1) return (double)(int32_t)unzig(rd_varint(r));
+    return __longlong_as_double((long long)rd_le(r, 8));
+}
+DEVI float rd_f32(Rd &r) { return __uint_as_float((uint32_t)rd_le(r, 4)); }
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_decompress(
+    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
+    const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status)
+{
+    constexpr int T = 64 * W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const DevDFrame fr = frames[ids[blockIdx.x]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = fr.n;
+    double *out = outp + fr.out_off;
+    const uint8_t *pay = body + fr.payload_off;
+
+    double *xs = (double *)(smem + P.o_xs);      // 8n : knot values / rle group values
+    float2 *tw = (float2 *)(smem + P.o_tw);      // 8L
+    unsigned char *AB = smem + P.o_a;            // >= 16L + 8 bytes, contiguous A|B
+    uint32_t *aux = (uint32_t *)(smem + P.o_aux);  // 4(n+2)
+    double *red = (double *)(smem + P.o_red);
+    // header scalars broadcast through LDS (written by lane 0)
+    struct Hdr {
+        double d0, d1;
+        uint32_t u0, u1, u2, bad;
+        float f0, f1;
+    };
+    Hdr *hdr = (Hdr *)(red + 40);
+
+    if (tid == 0) {
+        Rd r{pay, fr.payload_len, 0, false};
+        Hdr h;
+        h.d0 = h.d1 = 0.0; h.u0 = h.u1 = h.u2 = 0; h.f0 = h.f1 = 0.0f;
+        switch (fr.tag) {
+        case ATSC_CONSTANT: {
+            (void)rd_u8(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            if (bd > 3) r.bad = true;
+            else h.d0 = rd_value(r, bd);
+            break;
+        }
+        case ATSC_NOOP: {
+            (void)rd_u8(r);
+            const uint64_t cnt = rd_varint(r);
+            if (cnt != n) r.bad = true;
+            for (uint32_t i = 0; i < n && !r.bad; ++i) xs[i] = (double)unzig(rd_varint(r));
+            break;
+        }
+        case ATSC_POLYNOMIAL: {
+            const uint32_t id = (uint32_t)rd_varint(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            const uint64_t cnt = rd_varint(r);
+            if (id != 0 || bd > 3 || cnt > n) r.bad = true;
+            for (uint32_t i = 0; i < cnt && !r.bad; ++i) xs[i] = rd_value(r, bd);
+            h.d0 = __longlong_as_double((long long)rd_le(r, 8));  // min
+            h.d1 = __longlong_as_double((long long)rd_le(r, 8));  // max
+            h.u0 = (uint32_t)cnt;
+            h.u1 = rd_u8(r);  // point_step
+            break;
+        }
+        case ATSC_FFT: {
+            (void)rd_u8(r);
+            const uint64_t cnt = rd_varint(r);
+            if (cnt > P.bins) r.bad = true;
+            Sel *sel = (Sel *)AB;
+            for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
+                sel[i].pos = (uint32_t)rd_varint(r) & 0xffffu;
+                sel[i].re = rd_f32(r);
+                sel[i].im = rd_f32(r);
+            }
+            h.u0 = (uint32_t)cnt;
+            h.f0 = rd_f32(r);  // max_value
+            h.f1 = rd_f32(r);  // min_value
+            break;
+        }
+        case ATSC_RLE: {
+            (void)rd_u8(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            const uint64_t groups = rd_varint(r);
+            if (bd > 3 || groups > n) r.bad = true;
+            uint64_t *keys = (uint64_t *)AB;  // (run start << 32) | group
+            uint32_t e = 0;
+            for (uint32_t gi = 0; gi < groups && !r.bad; ++gi) {
+                xs[gi] = rd_value(r, bd);
+                const uint64_t cnt = rd_varint(r);
+                if (cnt > n - e) { r.bad = true; break; }
+                for (uint32_t k = 0; k < cnt && !r.bad; ++k) {
+                    const uint64_t idx = rd_varint(r);
+                    if (idx >= n) { r.bad = true; break; }
+                    keys[e++] = (idx << 32) | gi;
+                }
+            }
+            h.u0 = e;
+            break;
+        }
+        default: r.bad = true;
+        }
+        h.bad = r.bad ? 1u : 0u;
+        *hdr = h;
+        if (r.bad) atomicExch(status, 1);
+    }
+    __syncthreads();
+    const Hdr h = *hdr;
+    if (h.bad) return;
+
+    if (fr.tag == ATSC_CONSTANT) {
+        for (uint32_t j = tid; j < n; j += T) out[j] = h.d0;
+        return;
+    }
+    if (fr.tag == ATSC_NOOP) {
+        for (uint32_t j = tid; j < n; j += T) out[j] = xs[j];
+        return;
+    }
+    if (fr.tag == ATSC_POLYNOMIAL) {
+        const double mn = h.d0, mx = h.d1;
+        if (mx == mn) {  // polynomial.rs:396-399
+            for (uint32_t j = tid; j < n; j += T) out[j] = mx;
+            return;
+        }
+        const uint32_t step = h.u1, K = h.u0;
+        bool ok = step >= 1;
+        if (ok) {
+            const uint32_t cnt = (n + step - 1) / step;
+            const uint32_t Kp = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+            ok = (Kp == K) && K >= 2;
+        }
+        if (!ok) {  // a stream the reference's encoder cannot produce
+            if (tid == 0) atomicExch(status, 1);
+            return;
+        }
+        const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double sv = spline_eval([&](uint32_t k) { return xs[k]; }, j, n, step, K, magic);
+            double o = round(sv * 100000.0) / 100000.0;  // utils/mod.rs:66-74 (min first)
+            if (o < mn) o = mn;
+            else if (o > mx) o = mx;
+            out[j] = o;
+        }
+        return;
+    }
+    if (fr.tag == ATSC_FFT) {
+        const float mxf = h.f0, mnf = h.f1;
+        if (mxf == mnf) {  // fft.rs:427-430
+            for (uint32_t j = tid; j < n; j += T) out[j] = (double)mxf;
+            return;
+        }
+        // fft.rs:432-444: the decoder recomputes the Gibbs padding from the frame size
+        const uint32_t L = P.L, pre = P.pre;
+        const float2 *twp = twpool + P.tw_off;
+        for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
+        __syncthreads();
+        const Sel *sel = (const Sel *)AB;
+        const uint32_t K = h.u0;
+        const double mxd = (double)mxf, mnd = (double)mnf;
+        const float Lf = (float)L;
+        for (uint32_t j = tid; j < n; j += T) {
+            const uint32_t jj = j + pre;
+            double acc = 0.0;
+            for (uint32_t i = 0; i < K; ++i) {
+                const uint32_t pos = sel[i].pos;
+                if (pos >= L) continue;
+                const double re = (double)sel[i].re, im = (double)sel[i].im;
+                if (pos == 0) {
+                    acc += re;
+                } else {
+                    const float2 w = tw[(uint32_t)(((uint64_t)pos * jj) % L)];
+                    const double cf = (2 * pos == L) ? 1.0 : 2.0;  // fft.rs:401-422
+                    acc += cf * (re * (double)w.x - im * (double)w.y);
+                }
+            }
+            const float v = (float)acc / Lf;  // fft.rs:460  f.re / len (f32)
+            double o = round((double)v * 100000.0) / 100000.0;  // fft.rs:208-218 (max first)
+            if (o > mxd) o = mxd;
+            if (o < mnd) o = mnd;
+            out[j] = o;
+        }
+        return;
+    }
+    // RLE: rle.rs:204-236 -- sort (start, value) by start, then each sample takes the last run
+    // starting at or before it; samples before the first run stay 0.0
+    {
+        uint64_t *keys = (uint64_t *)AB;
+        const uint32_t E = h.u0;
+        uint32_t p2 = 1;
+        while (p2 < E) p2 <<= 1;
+        block_sort<W, true>(keys, nullptr, E, p2);
+        for (uint32_t j = tid; j < n; j += T) {
+            uint32_t lo = 0, hi = E;  // first entry with start > j
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)(keys[mid] >> 32) <= j) lo = mid + 1;
+                else hi = mid;
+            }
+            out[j] = lo ? xs[(uint32_t)(keys[lo - 1] & 0xffffffffu)] : 0.0;
+        }
+        (void)aux;
+    }
+}
+
+template <int W>
+static hipError_t launch_d(uint32_t count, uint32_t lds, const DevDFrame *frames,
+                           const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
+                           const uint8_t *body, double *out, int *status, hipStream_t s)
+{
+    auto kern = k_decompress<W>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, frames, ids, plans, twpool, body, out,
+                       status);
+    return hipGetLastError();
+}
+
+hipError_t launch_decompress(const DevDFrame *frames, uint64_t n_frames, const uint32_t *ids, int cls,
+                             uint32_t count, uint32_t lds, const DevPlan *plans,
+                             const float2 *twpool, const uint8_t *body, double *out, int *status,
+                             hipStream_t s)
+{
+    (void)n_frames;
+    if (count == 0) return hipSuccess;
+    switch (cls) {
+    case 0:
+    case 1:
+    case 2: return launch_d<1>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 3:
+    case 4: return launch_d<4>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 5: return launch_d<16>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace atsc

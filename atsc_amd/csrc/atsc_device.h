@@ -1,0 +1,279 @@
+// atsc_device.h -- device-side helpers shared by the compress and decompress kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atsc_hip.h"
+#include "atsc_internal.h"
+
+namespace atsc {
+
+#define DEVI __device__ __forceinline__
+
+// --------------------------------------------------------------------------------------------
+// Rust `as` casts (saturating, NaN -> 0) and bincode varints
+// --------------------------------------------------------------------------------------------
+DEVI int64_t sat_i64(double x)
+{
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+DEVI int32_t sat_i32(double x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483647.0) return INT32_MAX;
+    if (x <= -2147483648.0) return INT32_MIN;
+    return (int32_t)x;
+}
+DEVI int32_t sat_i16(double x)
+{
+    if (x != x) return 0;
+    if (x >= 32767.0) return 32767;
+    if (x <= -32768.0) return -32768;
+    return (int32_t)x;
+}
+DEVI uint32_t sat_u8(double x)
+{
+    if (x != x) return 0;
+    if (x >= 255.0) return 255;
+    if (x <= 0.0) return 0;
+    return (uint32_t)x;
+}
+DEVI uint32_t vlen(uint64_t v)
+{
+    return v < 251 ? 1u : v < (1ull << 16) ? 3u : v < (1ull << 32) ? 5u : 9u;
+}
+DEVI uint64_t zigzag(int64_t v)
+{
+    return v >= 0 ? ((uint64_t)v << 1) : ((~(uint64_t)v << 1) | 1ull);
+}
+DEVI uint32_t put_varint(uint8_t *p, uint64_t v)
+{
+    if (v < 251) {
+        p[0] = (uint8_t)v;
+        return 1;
+    }
+    uint32_t nb;
+    if (v < (1ull << 16)) { p[0] = 251; nb = 2; }
+    else if (v < (1ull << 32)) { p[0] = 252; nb = 4; }
+    else { p[0] = 253; nb = 8; }
+    for (uint32_t i = 0; i < nb; ++i) p[1 + i] = (uint8_t)(v >> (8 * i));
+    return nb + 1;
+}
+DEVI void put_u32(uint8_t *p, uint32_t u)
+{
+    p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); p[2] = (uint8_t)(u >> 16); p[3] = (uint8_t)(u >> 24);
+}
+DEVI void put_f32(uint8_t *p, float f) { put_u32(p, __float_as_uint(f)); }
+DEVI void put_u64(uint8_t *p, uint64_t u)
+{
+    put_u32(p, (uint32_t)u);
+    put_u32(p + 4, (uint32_t)(u >> 32));
+}
+DEVI void put_f64(uint8_t *p, double d) { put_u64(p, (uint64_t)__double_as_longlong(d)); }
+
+// optimizer/utils.rs:115-160  split_n: integer part and "fraction is non-zero"
+DEVI void split_n(double x, int64_t &ip, bool &frac_nz)
+{
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    const bool neg = ((int64_t)bits) < 0;
+    const int32_t exponent = (int32_t)((uint32_t)(bits >> 52) & 0x7ffu);
+    const uint64_t mant_u = (bits & ((1ull << 52) - 1)) | (1ull << 52);
+    const int64_t mant = neg ? -(int64_t)mant_u : (int64_t)mant_u;
+    const int32_t shl = exponent + (64 - 53 - 1023 + 1);
+    if (shl <= 0) {
+        const int32_t shr = -shl;
+        ip = 0;
+        frac_nz = (shr < 64) ? ((((uint64_t)mant) >> shr) != 0) : false;
+    } else if (shl < 64) {
+        ip = mant >> (64 - shl);
+        frac_nz = (((uint64_t)mant) << shl) != 0;
+    } else if (shl < 128) {
+        ip = (int64_t)(((uint64_t)mant) << (shl - 64));
+        frac_nz = false;
+    } else {
+        ip = 0;
+        frac_nz = false;
+    }
+}
+// optimizer/utils.rs:91-113 ; wire ids F64 0, I32 1, I16 2, U8 3
+DEVI uint32_t bitdepth_of(int64_t max_int, int64_t min_int)
+{
+    const int bd = max_int <= 255 ? 8 : max_int <= 32767 ? 16 : max_int <= 2147483647LL ? 32 : 64;
+    const int bs = (min_int >= 0 && min_int <= 255) ? 8
+                   : min_int >= -32768              ? 16
+                   : min_int >= -2147483648LL       ? 32
+                                                    : 64;
+    const int m = bd > bs ? bd : bs;
+    return m == 8 ? 3u : m == 16 ? 2u : m == 32 ? 1u : 0u;
+}
+// bytes one value takes at a bitdepth (constant.rs:43-60, polynomial.rs:61-81, rle.rs:46-63)
+DEVI uint32_t value_bytes(uint32_t bitdepth, double v)
+{
+    if (bitdepth == 3) return 1;
+    if (bitdepth == 2) return vlen(zigzag((int64_t)sat_i16(v)));
+    if (bitdepth == 1) return vlen(zigzag((int64_t)sat_i32(v)));
+    return 8;
+}
+DEVI uint32_t put_value(uint8_t *p, uint32_t bitdepth, double v)
+{
+    if (bitdepth == 3) { p[0] = (uint8_t)sat_u8(v); return 1; }
+    if (bitdepth == 2) return put_varint(p, zigzag((int64_t)sat_i16(v)));
+    if (bitdepth == 1) return put_varint(p, zigzag((int64_t)sat_i32(v)));
+    put_f64(p, v);
+    return 8;
+}
+
+// --------------------------------------------------------------------------------------------
+// workgroup collectives (W wavefronts).  All return the same bits in every thread.
+// --------------------------------------------------------------------------------------------
+template <int W>
+DEVI double block_sum_f64(double v, double *red, int &parity)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (W == 1) return v;
+    double *r = red + parity * 16;
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = r[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += r[w];
+    return s;
+}
+template <int W>
+DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (W == 1) return v;
+    uint32_t *r = (uint32_t *)(red + parity * 16);
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t s = r[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += r[w];
+    return s;
+}
+
+// In-place exclusive scan of an LDS u32 array; returns the total.  Each thread owns a
+// contiguous chunk; partials are scanned across the workgroup.
+template <int W>
+DEVI uint32_t block_excl_scan(uint32_t *arr, uint32_t count, uint32_t *wsum)
+{
+    constexpr int T = 64 * W;
+    const int tid = threadIdx.x;
+    const uint32_t C = (count + T - 1) / T;
+    const uint32_t b = min((uint32_t)tid * C, count), e = min(b + C, count);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += arr[i];
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if (W > 1) {
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+        incl += base;
+    }
+    if (tid == T - 1) wsum[W] = incl;
+    uint32_t run = incl - s;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t v = arr[i];
+        arr[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    const uint32_t total = wsum[W];
+    __syncthreads();
+    return total;
+}
+
+// Ascending-only bitonic network for any count (elements >= count act as +inf and never
+// move).  KeyOnly sorts u64 keys; otherwise a u32 payload array moves with the keys and
+// breaks ties (key, payload).
+template <int W, bool KeyOnly>
+DEVI void block_sort(uint64_t *keys, uint32_t *pay, uint32_t count, uint32_t P2)
+{
+    constexpr int T = 64 * W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t npairs = P2 >> 1;
+    auto ce = [&](uint32_t i, uint32_t l) {
+        if (l < count) {
+            const uint64_t a = keys[i], b = keys[l];
+            bool sw = a > b;
+            if (!KeyOnly) {
+                const uint32_t pa = pay[i], pb = pay[l];
+                sw = sw || (a == b && pa > pb);
+                if (sw) { pay[i] = pb; pay[l] = pa; }
+            }
+            if (sw) { keys[i] = b; keys[l] = a; }
+        }
+    };
+    uint32_t lk = 1;
+    for (uint32_t k = 2; k <= P2; k <<= 1, ++lk) {
+        const uint32_t half = k >> 1;
+        for (uint32_t t = tid; t < npairs; t += T) {
+            const uint32_t i = ((t >> (lk - 1)) << lk) | (t & (half - 1));
+            ce(i, i ^ (k - 1));
+        }
+        __syncthreads();
+        for (uint32_t j = half >> 1; j >= 1; j >>= 1) {
+            for (uint32_t t = tid; t < npairs; t += T) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                ce(i, i | j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Catmull-Rom / linear piecewise evaluation at integer x (splines 4.3.1 semantics, restated in
+// oracle/atsc_oracle.c spline_clamped_sample) with the closed-form segment index.
+// keys: T(k) = k*step for k < K-1, T(K-1) = n-1.   polynomial.rs:329-373
+// --------------------------------------------------------------------------------------------
+template <typename KnotFn>
+DEVI double spline_eval(KnotFn V, uint32_t i, uint32_t n, uint32_t step, uint32_t K, uint32_t magic)
+{
+    // V(k): value of knot k;  knot k sits at x = k*step, the last one (k = K-1) at x = n-1
+    if (i == n - 1) return V(K - 1);
+    uint32_t seg = __umulhi(i, magic);  // i / step
+    if (seg > K - 2) seg = K - 2;
+    const uint32_t t0i = seg * step;
+    const uint32_t t1i = (seg + 1 == K - 1) ? (n - 1) : (seg + 1) * step;
+    const double t0 = (double)t0i, t1 = (double)t1i;
+    const double v0 = V(seg), v1 = V(seg + 1);
+    const double nt = ((double)i - t0) / (t1 - t0);
+    if (seg > 0 && K - seg > 2) {
+        const uint32_t tmi = (seg - 1) * step;
+        const uint32_t tpi = (seg + 2 == K - 1) ? (n - 1) : (seg + 2) * step;
+        const double tm = (double)tmi, tp = (double)tpi;
+        const double vm = V(seg - 1), vp = V(seg + 2);
+        const double t2 = nt * nt;
+        const double t3 = t2 * nt;
+        const double two_t3 = t3 * 2.0;
+        const double two_t2 = t2 * 2.0;
+        const double three_t2 = t2 * 3.0;
+        const double m0 = (v1 - vm) / (t1 - tm) * (t1 - t0);
+        const double m1 = (vp - v0) / (tp - t0) * (t1 - t0);
+        return v0 * (two_t3 - three_t2 + 1.0) + m0 * (t3 - two_t2 + nt) + v1 * (three_t2 - two_t3) +
+               m1 * (t3 - t2);
+    }
+    return v0 * (1.0 - nt) + v1 * nt;
+}
+
+struct Sel {
+    uint32_t pos;
+    float re, im;
+};
+
+}  // namespace atsc

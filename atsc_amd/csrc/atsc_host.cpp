@@ -1,0 +1,737 @@
+// atsc_host.cpp -- host side of libatsc_hip.so: context, plans, launch orchestration and the
+// format helpers that sit either side of the GPU path.  There is NO CPU compression path in
+// this library: without a HIP device atsc_ctx_create fails with ATSC_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/atsc_hip.h"
+#include "atsc_internal.h"
+
+namespace atsc {
+hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
+                                 const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
+                                 const float2 *twpool, const KParams &prm, uint8_t *slots,
+                                 DevResult *res, atsc_frame_diag *diag, hipStream_t s);
+hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
+                       uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
+                       uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
+                       hipStream_t s);
+hipError_t launch_decompress(const struct DevDFrame *frames, uint64_t n_frames, const uint32_t *ids,
+                             int cls, uint32_t count, uint32_t lds, const DevPlan *plans,
+                             const float2 *twpool, const uint8_t *body, double *out, int *status,
+                             hipStream_t s);
+}  // namespace atsc
+
+using namespace atsc;
+
+static const int N_CLASSES = 6;
+static const uint32_t MAX_FRAME_TIER_M = 4096;  // larger frames need the global-memory FFT tier
+
+struct atsc_ctx {
+    int device = 0;
+    std::string last_error;
+    // diagnostics of the last compress call
+    atsc_frame_diag *d_diag = nullptr;
+    uint64_t diag_cap = 0;
+    uint64_t diag_n = 0;
+    hipStream_t diag_stream = nullptr;
+    bool want_diag = false;
+};
+
+struct PlanTables {
+    std::vector<DevPlan> plans;   // host copy
+    std::vector<float2> twpool;   // host copy
+    std::map<uint32_t, uint32_t> by_n;
+    DevPlan *d_plans = nullptr;
+    float2 *d_tw = nullptr;
+};
+
+struct atsc_plan {
+    atsc_ctx *ctx = nullptr;
+    uint64_t n_frames = 0, n_samples = 0, body_bound = 0, slot_bytes = 0;
+    PlanTables tabs;
+    std::vector<uint32_t> class_count, class_lds, class_first;
+    DevFrame *d_frames = nullptr;
+    uint32_t *d_ids = nullptr;
+    DevResult *d_res = nullptr;
+    uint8_t *d_slots = nullptr;
+    uint32_t *d_local = nullptr;
+    uint64_t *d_blocksum = nullptr;
+};
+
+struct atsc_dplan {
+    atsc_ctx *ctx = nullptr;
+    uint64_t n_frames = 0, n_samples = 0;
+    PlanTables tabs;
+    std::vector<uint32_t> class_count, class_lds, class_first;
+    DevDFrame *d_frames = nullptr;
+    uint32_t *d_ids = nullptr;
+    int *d_status = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+static int fail(atsc_ctx *ctx, int rc, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return rc;
+}
+#define HIPCHK(ctx, call)                                                    \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return fail((ctx), ATSC_E_HIP, #call, e__);   \
+    } while (0)
+
+static bool is_decomposable(uint64_t n)
+{
+    if (n == 0) return false;
+    while (n % 2 == 0) n /= 2;
+    while (n % 3 == 0) n /= 3;
+    return n == 1;
+}
+static uint32_t pow2_ge(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+static uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+extern "C" uint64_t atsc_next_size(uint64_t n)
+{
+    n += 1;
+    while (!is_decomposable(n)) n += 1;
+    return n;
+}
+
+extern "C" uint64_t atsc_payload_bound_bytes(uint64_t n)
+{
+    // worst case over codecs: RLE with every value distinct  2 + varint(D) + n*(8 + 1 + varint(idx));
+    // Noop 1 + varint(n) + 9n ; Polynomial store-all 2 + varint(n) + 8n + 17
+    return 32 + 14 * n;
+}
+
+static int class_of(uint32_t n, uint32_t L)
+{
+    if (L <= 128) return 0;                               // <1,2>
+    if (L <= 320) return 1;                               // <1,5>
+    if (L <= 576) return 2;                               // <1,9>
+    if (L <= 1280) return 3;                              // <4,5>
+    if (L <= 2304) return 4;                              // <4,9>
+    if (L <= 5120 && n <= MAX_FRAME_TIER_M) return 5;     // <16,5>
+    return -1;
+}
+
+// Fills the per-length table entry (see DevPlan) and appends the twiddle table of L if new.
+static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64_t> &tw_by_L)
+{
+    DevPlan p;
+    memset(&p, 0, sizeof(p));
+    p.n = n;
+    if (n >= 128) {  // fft.rs:305-309
+        p.L = (uint32_t)atsc_next_size(n);
+        p.pre = (p.L - n) / 2;
+        p.direct = 0;
+    } else {
+        p.L = n;
+        p.pre = 0;
+        p.direct = 1;
+    }
+    p.bins = p.L / 2 + 1;
+    p.mf = (3 >= n / 100) ? 3 : n / 100;
+    p.dk1 = std::max(p.mf / 2, 1u);
+    p.dk2 = std::max(p.mf / 10, 1u);
+    p.kcap = std::min(p.bins, p.mf + 17 * p.dk1 + 5 * p.dk2);
+    if (!p.direct) {
+        uint32_t l = p.L, s = 0;
+        while (l % 4 == 0) { p.radix[s++] = 4; l /= 4; }
+        while (l % 2 == 0) { p.radix[s++] = 2; l /= 2; }
+        while (l % 3 == 0) { p.radix[s++] = 3; l /= 3; }
+        if (l != 1 || s > 14) return ATSC_E_INVALID;
+        p.nstages = s;
+    }
+    p.p2bins = pow2_ge(p.bins);
+    p.p2n = pow2_ge(n);
+    uint32_t o = 0;
+    p.o_red = o; o += 512;
+    p.o_xs = o; o += align16(8 * n);
+    p.o_tw = o; o += align16(8 * std::max(p.L, n));  // also hosts two u32[n] arrays for RLE
+    p.o_a = o; o += align16(8 * std::max(p.L, n));
+    p.o_b = o; o += align16(8 * std::max(p.L, n) + 8);
+    p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
+    p.o_aux = o; o += align16(4 * (n + 2));
+    p.lds_bytes = o;
+    auto it = tw_by_L.find(p.L);
+    if (it == tw_by_L.end()) {
+        const uint64_t off = T.twpool.size();
+        tw_by_L[p.L] = off;
+        p.tw_off = off;
+        T.twpool.resize(off + p.L);
+        for (uint32_t t = 0; t < p.L; ++t) {
+            const double a = 2.0 * 3.14159265358979323846 * (double)t / (double)p.L;
+            T.twpool[off + t] = make_float2((float)cos(a), (float)sin(a));
+        }
+    } else {
+        p.tw_off = it->second;
+    }
+    T.by_n[n] = (uint32_t)T.plans.size();
+    T.plans.push_back(p);
+    return ATSC_OK;
+}
+
+static int upload_tables(atsc_ctx *ctx, PlanTables &T)
+{
+    HIPCHK(ctx, hipMalloc((void **)&T.d_plans, std::max<size_t>(1, T.plans.size()) * sizeof(DevPlan)));
+    HIPCHK(ctx, hipMemcpy(T.d_plans, T.plans.data(), T.plans.size() * sizeof(DevPlan),
+                          hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&T.d_tw, std::max<size_t>(1, T.twpool.size()) * sizeof(float2)));
+    HIPCHK(ctx, hipMemcpy(T.d_tw, T.twpool.data(), T.twpool.size() * sizeof(float2),
+                          hipMemcpyHostToDevice));
+    return ATSC_OK;
+}
+static void free_tables(PlanTables &T)
+{
+    if (T.d_plans) (void)hipFree(T.d_plans);
+    if (T.d_tw) (void)hipFree(T.d_tw);
+    T.d_plans = nullptr;
+    T.d_tw = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// public: misc
+// ------------------------------------------------------------------------------------------
+extern "C" const char *atsc_version(void) { return "atsc-mi355x 0.1 (gfx950)"; }
+
+extern "C" const char *atsc_strerror(int rc)
+{
+    switch (rc) {
+    case ATSC_OK: return "ok";
+    case ATSC_E_INVALID: return "invalid argument";
+    case ATSC_E_NOMEM: return "out of memory";
+    case ATSC_E_UNSUPPORTED:
+        return "not implemented on the GPU path yet (frames > 4096 samples, IDW, sample levels > 0, "
+               "unbounded fft/polynomial)";
+    case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case ATSC_E_HIP: return "HIP runtime error";
+    case ATSC_E_CAPACITY: return "output buffer too small";
+    case ATSC_E_FORMAT: return "malformed input bytes";
+    case ATSC_E_VERSION: return "BRO version is newer than this library";
+    case ATSC_E_IO: return "i/o error";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
+{
+    if (!out) return ATSC_E_INVALID;
+    *out = nullptr;
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) return ATSC_E_NO_DEVICE;
+    if (device < 0 || device >= cnt) return ATSC_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return ATSC_E_NO_DEVICE;
+    atsc_ctx *c = new (std::nothrow) atsc_ctx();
+    if (!c) return ATSC_E_NOMEM;
+    c->device = device;
+    c->want_diag = getenv("ATSC_DIAG") != nullptr;
+    *out = c;
+    return ATSC_OK;
+}
+extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+    delete ctx;
+}
+extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : "";
+}
+// Diagnostics are opt-in (they add 40 B/frame of HBM writes): enabled by this call.
+extern "C" int atsc_ctx_enable_diag(atsc_ctx *ctx, int on)
+{
+    if (!ctx) return ATSC_E_INVALID;
+    ctx->want_diag = on != 0;
+    return ATSC_OK;
+}
+extern "C" int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t n_frames)
+{
+    if (!ctx || !out) return ATSC_E_INVALID;
+    if (!ctx->d_diag || ctx->diag_n != n_frames) return fail(ctx, ATSC_E_INVALID, "no diagnostics recorded");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->diag_stream));
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_diag, n_frames * sizeof(atsc_frame_diag), hipMemcpyDeviceToHost));
+    return ATSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// compress plan
+// ------------------------------------------------------------------------------------------
+extern "C" void atsc_plan_destroy(atsc_plan *p)
+{
+    if (!p) return;
+    free_tables(p->tabs);
+    if (p->d_frames) (void)hipFree(p->d_frames);
+    if (p->d_ids) (void)hipFree(p->d_ids);
+    if (p->d_res) (void)hipFree(p->d_res);
+    if (p->d_slots) (void)hipFree(p->d_slots);
+    if (p->d_local) (void)hipFree(p->d_local);
+    if (p->d_blocksum) (void)hipFree(p->d_blocksum);
+    delete p;
+}
+
+extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64_t n_frames,
+                                atsc_plan **out)
+{
+    if (!ctx || !frame_off || !out || n_frames == 0) return fail(ctx, ATSC_E_INVALID, "plan_create: bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    atsc_plan *p = new (std::nothrow) atsc_plan();
+    if (!p) return ATSC_E_NOMEM;
+    p->ctx = ctx;
+    p->n_frames = n_frames;
+    std::vector<DevFrame> frames(n_frames);
+    std::vector<int> cls(n_frames);
+    std::map<uint32_t, uint64_t> tw_by_L;
+    p->class_count.assign(N_CLASSES, 0);
+    p->class_lds.assign(N_CLASSES, 0);
+    p->class_first.assign(N_CLASSES, 0);
+    uint64_t slot = 0, bound = 0;
+    for (uint64_t f = 0; f < n_frames; ++f) {
+        if (frame_off[f + 1] <= frame_off[f]) {
+            atsc_plan_destroy(p);
+            return fail(ctx, ATSC_E_INVALID, "plan_create: empty or unordered frame");
+        }
+        const uint64_t n64 = frame_off[f + 1] - frame_off[f];
+        if (n64 > MAX_FRAME_TIER_M) {
+            atsc_plan_destroy(p);
+            return fail(ctx, ATSC_E_UNSUPPORTED, "plan_create: frame longer than 4096 samples");
+        }
+        const uint32_t n = (uint32_t)n64;
+        auto it = p->tabs.by_n.find(n);
+        uint32_t pi;
+        if (it == p->tabs.by_n.end()) {
+            int rc = build_plan_entry(n, p->tabs, tw_by_L);
+            if (rc) { atsc_plan_destroy(p); return fail(ctx, rc, "plan_create: plan entry"); }
+            pi = p->tabs.by_n[n];
+        } else {
+            pi = it->second;
+        }
+        const DevPlan &dp = p->tabs.plans[pi];
+        const int c = class_of(n, dp.L);
+        if (c < 0) { atsc_plan_destroy(p); return fail(ctx, ATSC_E_UNSUPPORTED, "plan_create: frame class"); }
+        cls[f] = c;
+        p->class_count[c]++;
+        p->class_lds[c] = std::max(p->class_lds[c], dp.lds_bytes);
+        frames[f].sample_off = frame_off[f];
+        frames[f].slot_off = slot;
+        frames[f].n = n;
+        frames[f].plan = pi;
+        const uint64_t pb = atsc_payload_bound_bytes(n);
+        slot += (pb + 15) & ~15ull;
+        bound += pb + 16;
+    }
+    p->n_samples = frame_off[n_frames] - frame_off[0];
+    p->slot_bytes = slot;
+    p->body_bound = bound;
+    // frame ids grouped by class
+    std::vector<uint32_t> ids(n_frames);
+    {
+        uint32_t acc = 0;
+        for (int c = 0; c < N_CLASSES; ++c) { p->class_first[c] = acc; acc += p->class_count[c]; }
+        std::vector<uint32_t> cur(p->class_first);
+        for (uint64_t f = 0; f < n_frames; ++f) ids[cur[cls[f]]++] = (uint32_t)f;
+    }
+    int rc = upload_tables(ctx, p->tabs);
+    if (rc) { atsc_plan_destroy(p); return rc; }
+    const uint32_t nb = (uint32_t)((n_frames + 1023) / 1024);
+#define PCHK(call)                                                                     \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) { atsc_plan_destroy(p); return fail(ctx, ATSC_E_HIP, #call, e__); } \
+    } while (0)
+    PCHK(hipMalloc((void **)&p->d_frames, n_frames * sizeof(DevFrame)));
+    PCHK(hipMemcpy(p->d_frames, frames.data(), n_frames * sizeof(DevFrame), hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&p->d_ids, n_frames * sizeof(uint32_t)));
+    PCHK(hipMemcpy(p->d_ids, ids.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&p->d_res, n_frames * sizeof(DevResult)));
+    PCHK(hipMalloc((void **)&p->d_slots, std::max<uint64_t>(slot, 16)));
+    PCHK(hipMalloc((void **)&p->d_local, n_frames * sizeof(uint32_t)));
+    PCHK(hipMalloc((void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
+#undef PCHK
+    *out = p;
+    return ATSC_OK;
+}
+extern "C" uint64_t atsc_plan_n_frames(const atsc_plan *p) { return p ? p->n_frames : 0; }
+extern "C" uint64_t atsc_plan_n_samples(const atsc_plan *p) { return p ? p->n_samples : 0; }
+extern "C" uint64_t atsc_plan_body_bound(const atsc_plan *p) { return p ? p->body_bound : 0; }
+
+extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
+                                      int compressor, int bounded, float max_error, int sample_level,
+                                      uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
+                                      uint8_t *d_chosen, double *d_err, void *stream)
+{
+    if (!ctx || !plan || !d_samples || !d_body || !d_rec_off) return fail(ctx, ATSC_E_INVALID, "compress: null argument");
+    if (sample_level < 0 || sample_level > 6) return fail(ctx, ATSC_E_INVALID, "compress: sample level");
+    switch (compressor) {
+    case ATSC_AUTO:
+        if (!bounded) return fail(ctx, ATSC_E_INVALID, "compress: Auto needs the bounded path (compressor/mod.rs:72 todo!())");
+        if (sample_level != 0) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: sample level > 0");
+        break;
+    case ATSC_FFT:
+    case ATSC_POLYNOMIAL:
+        if (!bounded) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: unbounded fft/polynomial");
+        break;
+    case ATSC_NOOP:
+    case ATSC_CONSTANT:
+    case ATSC_RLE:
+        break;
+    case ATSC_IDW:
+        return fail(ctx, ATSC_E_UNSUPPORTED, "compress: idw");
+    default:
+        return fail(ctx, ATSC_E_INVALID, "compress: unknown compressor id");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    KParams prm;
+    prm.max_err = (double)max_error;  // frame/mod.rs:67,118: `max_error as f64`
+    prm.poly_target = std::round(prm.max_err * 1000.0) / 1000.0;  // polynomial.rs:230
+    {
+        const double v = prm.max_err * 1000.0;  // fft.rs:334 `as i32` saturates, NaN -> 0
+        prm.max_err_m = (v != v) ? 0 : v >= 2147483647.0 ? INT32_MAX : v <= -2147483648.0 ? INT32_MIN : (int32_t)v;
+    }
+    prm.mode = compressor;
+    prm.bounded = bounded;
+    prm.want_diag = ctx->want_diag;
+    atsc_frame_diag *d_diag = nullptr;
+    if (ctx->want_diag) {
+        if (ctx->diag_cap < plan->n_frames) {
+            if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+            ctx->d_diag = nullptr;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_diag, plan->n_frames * sizeof(atsc_frame_diag)));
+            ctx->diag_cap = plan->n_frames;
+        }
+        ctx->diag_n = plan->n_frames;
+        ctx->diag_stream = s;
+        d_diag = ctx->d_diag;
+    }
+    for (int c = 0; c < N_CLASSES; ++c) {
+        if (!plan->class_count[c]) continue;
+        hipError_t e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
+                                             plan->d_frames, plan->d_ids + plan->class_first[c],
+                                             plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
+                                             plan->d_res, d_diag, s);
+        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
+    }
+    hipError_t e = launch_pack(plan->d_frames, plan->d_res, plan->n_frames, plan->d_local,
+                               plan->d_blocksum, plan->d_slots, d_body, body_cap, d_rec_off,
+                               d_chosen, d_err, s);
+    if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
+    return ATSC_OK;
+}
+
+extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                                    uint64_t n_frames, int compressor, int bounded, float max_error,
+                                    int sample_level, uint8_t *body, uint64_t body_cap,
+                                    uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen,
+                                    double *err)
+{
+    if (!ctx || !samples || !frame_off || !body || !body_len) return fail(ctx, ATSC_E_INVALID, "compress_frames: null argument");
+    if (n_frames == 0) return fail(ctx, ATSC_E_INVALID, "compress_frames: no frames");
+    // re-base offsets so that frame_off[0] maps to d_x[0]
+    std::vector<uint64_t> rel(n_frames + 1);
+    for (uint64_t i = 0; i <= n_frames; ++i) rel[i] = frame_off[i] - frame_off[0];
+    atsc_plan *plan = nullptr;
+    int rc = atsc_plan_create(ctx, rel.data(), n_frames, &plan);
+    if (rc) return rc;
+    const uint64_t ns = rel[n_frames];
+    const uint64_t bound = atsc_plan_body_bound(plan);
+    double *d_x = nullptr, *d_err = nullptr;
+    uint8_t *d_body = nullptr, *d_ch = nullptr;
+    uint64_t *d_off = nullptr;
+    std::vector<uint64_t> h_off(n_frames + 1);
+    hipError_t e = hipSuccess;
+#define FCHK(call)                                            \
+    do {                                                      \
+        e = (call);                                           \
+        if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
+    } while (0)
+    FCHK(hipMalloc((void **)&d_x, ns * sizeof(double)));
+    FCHK(hipMalloc((void **)&d_body, std::max<uint64_t>(bound, 16)));
+    FCHK(hipMalloc((void **)&d_off, (n_frames + 1) * sizeof(uint64_t)));
+    FCHK(hipMalloc((void **)&d_ch, n_frames));
+    FCHK(hipMalloc((void **)&d_err, n_frames * sizeof(double)));
+    FCHK(hipMemcpy(d_x, samples + frame_off[0], ns * sizeof(double), hipMemcpyHostToDevice));
+    rc = atsc_compress_plan_dev(ctx, plan, d_x, compressor, bounded, max_error, sample_level, d_body,
+                                bound, d_off, d_ch, d_err, nullptr);
+    if (rc) goto done;
+    FCHK(hipStreamSynchronize(nullptr));
+    FCHK(hipMemcpy(h_off.data(), d_off, (n_frames + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *body_len = h_off[n_frames];
+    if (h_off[n_frames] > body_cap) { rc = fail(ctx, ATSC_E_CAPACITY, "compress_frames: body_cap"); goto done; }
+    FCHK(hipMemcpy(body, d_body, h_off[n_frames], hipMemcpyDeviceToHost));
+    if (rec_off) memcpy(rec_off, h_off.data(), (n_frames + 1) * sizeof(uint64_t));
+    if (chosen) FCHK(hipMemcpy(chosen, d_ch, n_frames, hipMemcpyDeviceToHost));
+    if (err) FCHK(hipMemcpy(err, d_err, n_frames * sizeof(double), hipMemcpyDeviceToHost));
+#undef FCHK
+done:
+    if (d_x) (void)hipFree(d_x);
+    if (d_body) (void)hipFree(d_body);
+    if (d_off) (void)hipFree(d_off);
+    if (d_ch) (void)hipFree(d_ch);
+    if (d_err) (void)hipFree(d_err);
+    atsc_plan_destroy(plan);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side format helpers
+// ------------------------------------------------------------------------------------------
+static uint64_t prev_power_of_two(uint64_t n)
+{
+    const uint64_t v = n | 1;
+    const int hi = 63 - __builtin_clzll(v);
+    return (1ull << hi) & n;
+}
+extern "C" uint64_t atsc_chunk_sizes(uint64_t len, uint64_t *out, uint64_t cap)
+{
+    uint64_t k = 0;
+    while (len > 0) {
+        uint64_t sz;
+        if (len >= 131072) sz = 131072;
+        else if (len <= 512) sz = len;
+        else sz = prev_power_of_two(len);
+        if (out && k < cap) out[k] = sz;
+        ++k;
+        len -= sz;
+    }
+    return k;
+}
+extern "C" uint64_t atsc_clean_data(const double *in, uint64_t n, double *out)
+{
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        if (!(std::isnan(in[i]) || std::isinf(in[i]))) out[k++] = in[i];
+    return k;
+}
+static uint32_t host_put_varint(uint8_t *p, uint64_t v)
+{
+    if (v < 251) { p[0] = (uint8_t)v; return 1; }
+    uint32_t nb;
+    if (v < (1ull << 16)) { p[0] = 251; nb = 2; }
+    else if (v < (1ull << 32)) { p[0] = 252; nb = 4; }
+    else { p[0] = 253; nb = 8; }
+    for (uint32_t i = 0; i < nb; ++i) p[1 + i] = (uint8_t)(v >> (8 * i));
+    return nb + 1;
+}
+static bool host_get_varint(const uint8_t *b, uint64_t len, uint64_t &pos, uint64_t &v)
+{
+    if (pos >= len) return false;
+    const uint8_t t = b[pos];
+    uint32_t nb;
+    if (t < 251) { v = t; pos += 1; return true; }
+    if (t == 251) nb = 2;
+    else if (t == 252) nb = 4;
+    else if (t == 253) nb = 8;
+    else return false;
+    if (pos + 1 + nb > len) return false;
+    v = 0;
+    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)b[pos + 1 + i] << (8 * i);
+    pos += 1 + nb;
+    return true;
+}
+extern "C" uint64_t atsc_bro_prefix(uint64_t n_frames, uint8_t *out)
+{
+    memcpy(out, "BRRO", 4);
+    const uint32_t ver = 1;
+    memcpy(out + 4, &ver, 4);
+    out[8] = (uint8_t)(n_frames & 0xff);  // u8 += 1 per frame, wraps (header.rs:52-54)
+    return 9 + host_put_varint(out + 9, n_frames);
+}
+extern "C" int atsc_bro_open(const uint8_t *bro, uint64_t len, uint64_t *body_off, uint64_t *n_frames)
+{
+    if (!bro || len < 9) return ATSC_E_FORMAT;
+    if (memcmp(bro, "BRRO", 4) != 0) return ATSC_E_FORMAT;
+    uint32_t ver;
+    memcpy(&ver, bro + 4, 4);
+    if (ver > 1) return ATSC_E_VERSION;
+    uint64_t pos = 9, nf = 0;
+    if (!host_get_varint(bro, len, pos, nf)) return ATSC_E_FORMAT;
+    if (body_off) *body_off = pos;
+    if (n_frames) *n_frames = nf;
+    return ATSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// decompress plan
+// ------------------------------------------------------------------------------------------
+extern "C" void atsc_dplan_destroy(atsc_dplan *p)
+{
+    if (!p) return;
+    free_tables(p->tabs);
+    if (p->d_frames) (void)hipFree(p->d_frames);
+    if (p->d_ids) (void)hipFree(p->d_ids);
+    if (p->d_status) (void)hipFree(p->d_status);
+    delete p;
+}
+extern "C" uint64_t atsc_dplan_n_frames(const atsc_dplan *p) { return p ? p->n_frames : 0; }
+extern "C" uint64_t atsc_dplan_n_samples(const atsc_dplan *p) { return p ? p->n_samples : 0; }
+
+extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
+                                 int has_count, atsc_dplan **out)
+{
+    if (!ctx || !body || !out) return fail(ctx, ATSC_E_INVALID, "dplan_create: null argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    uint64_t pos = 0, declared = 0;
+    if (has_count && !host_get_varint(body, body_len, pos, declared))
+        return fail(ctx, ATSC_E_FORMAT, "dplan_create: frame count");
+    atsc_dplan *p = new (std::nothrow) atsc_dplan();
+    if (!p) return ATSC_E_NOMEM;
+    p->ctx = ctx;
+    std::vector<DevDFrame> frames;
+    std::vector<int> cls;
+    std::map<uint32_t, uint64_t> tw_by_L;
+    p->class_count.assign(N_CLASSES, 0);
+    p->class_lds.assign(N_CLASSES, 0);
+    p->class_first.assign(N_CLASSES, 0);
+    uint64_t out_off = 0;
+    while (has_count ? frames.size() < declared : pos < body_len) {
+        uint64_t fs, sc, tag, dl;
+        if (!host_get_varint(body, body_len, pos, fs) || !host_get_varint(body, body_len, pos, sc) ||
+            !host_get_varint(body, body_len, pos, tag) || !host_get_varint(body, body_len, pos, dl) ||
+            pos + dl > body_len) {
+            atsc_dplan_destroy(p);
+            return fail(ctx, ATSC_E_FORMAT, "dplan_create: truncated frame record");
+        }
+        if (tag > 6 || tag == ATSC_AUTO) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: compressor id"); }
+        if (tag == ATSC_IDW) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: idw frame"); }
+        uint64_t nout = sc;
+        if (tag == ATSC_NOOP) {
+            // noop_to_data returns the stored vector whatever sample_count says (noop.rs:79-83)
+            uint64_t q = pos + 1, cnt = 0;
+            if (dl < 2 || !host_get_varint(body, pos + dl, q, cnt)) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: noop payload"); }
+            nout = cnt;
+        }
+        if (nout == 0 || nout > MAX_FRAME_TIER_M) {
+            atsc_dplan_destroy(p);
+            return fail(ctx, nout == 0 ? ATSC_E_FORMAT : ATSC_E_UNSUPPORTED, "dplan_create: frame sample count");
+        }
+        const uint32_t n = (uint32_t)nout;
+        auto it = p->tabs.by_n.find(n);
+        uint32_t pi;
+        if (it == p->tabs.by_n.end()) {
+            int rc = build_plan_entry(n, p->tabs, tw_by_L);
+            if (rc) { atsc_dplan_destroy(p); return fail(ctx, rc, "dplan_create: plan entry"); }
+            pi = p->tabs.by_n[n];
+        } else {
+            pi = it->second;
+        }
+        const DevPlan &dp = p->tabs.plans[pi];
+        const int c = class_of(n, dp.L);
+        if (c < 0) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: frame class"); }
+        DevDFrame d;
+        d.payload_off = pos;
+        d.out_off = out_off;
+        d.payload_len = (uint32_t)dl;
+        d.n = n;
+        d.tag = (uint32_t)tag;
+        d.plan = pi;
+        frames.push_back(d);
+        cls.push_back(c);
+        p->class_count[c]++;
+        p->class_lds[c] = std::max(p->class_lds[c], dp.lds_bytes);
+        out_off += n;
+        pos += dl;
+    }
+    if (frames.empty()) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: no frames"); }
+    p->n_frames = frames.size();
+    p->n_samples = out_off;
+    std::vector<uint32_t> ids(frames.size());
+    {
+        uint32_t acc = 0;
+        for (int c = 0; c < N_CLASSES; ++c) { p->class_first[c] = acc; acc += p->class_count[c]; }
+        std::vector<uint32_t> cur(p->class_first);
+        for (size_t f = 0; f < frames.size(); ++f) ids[cur[cls[f]]++] = (uint32_t)f;
+    }
+    int rc = upload_tables(ctx, p->tabs);
+    if (rc) { atsc_dplan_destroy(p); return rc; }
+#define PCHK(call)                                                                      \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_HIP, #call, e__); } \
+    } while (0)
+    PCHK(hipMalloc((void **)&p->d_frames, frames.size() * sizeof(DevDFrame)));
+    PCHK(hipMemcpy(p->d_frames, frames.data(), frames.size() * sizeof(DevDFrame), hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&p->d_ids, ids.size() * sizeof(uint32_t)));
+    PCHK(hipMemcpy(p->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
+    PCHK(hipMemset(p->d_status, 0, sizeof(int)));
+#undef PCHK
+    *out = p;
+    return ATSC_OK;
+}
+
+extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t *d_body,
+                                        double *d_out, void *stream)
+{
+    if (!ctx || !dp || !d_body || !d_out) return fail(ctx, ATSC_E_INVALID, "decompress: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (int c = 0; c < N_CLASSES; ++c) {
+        if (!dp->class_count[c]) continue;
+        hipError_t e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
+                                         dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,
+                                         dp->tabs.d_tw, d_body, d_out, dp->d_status, s);
+        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_decompress", e);
+    }
+    return ATSC_OK;
+}
+
+extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
+                                      int has_count, double *out, uint64_t out_cap, uint64_t *out_n)
+{
+    if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
+    atsc_dplan *dp = nullptr;
+    int rc = atsc_dplan_create(ctx, body, body_len, has_count, &dp);
+    if (rc) return rc;
+    *out_n = dp->n_samples;
+    if (dp->n_samples > out_cap) { atsc_dplan_destroy(dp); return fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap"); }
+    uint8_t *d_body = nullptr;
+    double *d_out = nullptr;
+    int status = 0;
+    hipError_t e = hipSuccess;
+#define FCHK(call)                                            \
+    do {                                                      \
+        e = (call);                                           \
+        if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
+    } while (0)
+    FCHK(hipMalloc((void **)&d_body, std::max<uint64_t>(body_len, 16)));
+    FCHK(hipMalloc((void **)&d_out, dp->n_samples * sizeof(double)));
+    FCHK(hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice));
+    rc = atsc_decompress_plan_dev(ctx, dp, d_body, d_out, nullptr);
+    if (rc) goto done;
+    FCHK(hipStreamSynchronize(nullptr));
+    FCHK(hipMemcpy(&status, dp->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) { rc = fail(ctx, ATSC_E_FORMAT, "decompress_frames: malformed payload"); goto done; }
+    FCHK(hipMemcpy(out, d_out, dp->n_samples * sizeof(double), hipMemcpyDeviceToHost));
+#undef FCHK
+done:
+    if (d_body) (void)hipFree(d_body);
+    if (d_out) (void)hipFree(d_out);
+    atsc_dplan_destroy(dp);
+    return rc;
+}

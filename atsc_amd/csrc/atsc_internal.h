@@ -1,0 +1,66 @@
+// Internal structures shared by the host glue and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace atsc {
+
+// One entry per distinct frame length in a plan.  Everything the kernels need that
+// depends only on n (reference: fft.rs:298-311, utils/mod.rs:32-49, polynomial.rs:220-224).
+struct DevPlan {
+    uint32_t n;        // samples in the frame
+    uint32_t L;        // transform length: next_size(n) if n >= 128 else n  (fft.rs:305-311)
+    uint32_t pre;      // Gibbs prefix padding (fft.rs:187-190)
+    uint32_t bins;     // L/2 + 1 (fft.rs:327)
+    uint32_t mf;       // max(3, n/100) (fft.rs:298-302)
+    uint32_t dk1;      // max(mf/2, 1)  (fft.rs:349)
+    uint32_t dk2;      // max(mf/10, 1) (fft.rs:350)
+    uint32_t kcap;     // min(bins, mf + 17*dk1 + 5*dk2): most bins the ladder can ever store
+    uint32_t direct;   // 1: O(n^2) DFT (n < 128, any n incl. primes); 0: Stockham 2^a 3^b
+    uint32_t nstages;
+    uint32_t radix[14];
+    uint32_t p2bins;   // power of two >= bins (sort network size)
+    uint32_t p2n;      // power of two >= n
+    uint32_t lds_bytes;
+    // LDS carve offsets (bytes, 16-aligned)
+    uint32_t o_xs, o_tw, o_a, o_b, o_sel, o_aux, o_red;
+    uint64_t tw_off;   // offset (in float2 entries) of this L's table in the twiddle pool
+};
+
+struct DevFrame {
+    uint64_t sample_off;
+    uint64_t slot_off;  // byte offset of the frame's payload slot in the scratch arena
+    uint32_t n;
+    uint32_t plan;
+};
+
+struct DevResult {
+    double err;
+    uint32_t len;     // payload bytes in the slot
+    uint32_t chosen;  // compressor wire id
+};
+
+struct KParams {
+    double max_err;      // (double)(float) max_error
+    double poly_target;  // round_f64(max_err, 3)  (polynomial.rs:230)
+    int32_t max_err_m;   // (max_err * 1000.0) as i32  (fft.rs:334)
+    int32_t mode;        // ATSC_* compressor id
+    int32_t bounded;
+    int32_t want_diag;
+};
+
+// parsed frame record for decompression
+struct DevDFrame {
+    uint64_t payload_off;  // byte offset of the payload in the body
+    uint64_t out_off;      // sample offset in the output
+    uint32_t payload_len;
+    uint32_t n;            // sample_count
+    uint32_t tag;          // compressor id
+    uint32_t plan;         // index into DevPlan table (by n)
+};
+
+static inline uint32_t varint_len_u64(uint64_t v)
+{
+    return v < 251 ? 1u : v < (1ull << 16) ? 3u : v < (1ull << 32) ? 5u : 9u;
+}
+
+}  // namespace atsc

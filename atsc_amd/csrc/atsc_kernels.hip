@@ -1,0 +1,746 @@
+// atsc_kernels.hip -- hand-written gfx950 kernels for the ATSC per-frame compressor path.
+//
+// One workgroup of W wavefronts (64 lanes each) owns one frame.  The frame's f64 samples,
+// the twiddle table of its transform length and two complex-f32 work buffers live in LDS;
+// each lane keeps its share of the (Gibbs padded) samples in registers for the error ladders.
+//
+// What replaces what (reference paths relative to the instaclustr/atsc repository root):
+//   stats_phase        DataStats::new / bitdepth / split_n      atsc/src/optimizer/utils.rs:39-160
+//   fft_forward        rustfft forward plan + process            atsc/src/compressor/fft.rs:315-323
+//   sort + ladder      fft_trim + mirrored iFFT + round + MAPE   atsc/src/compressor/fft.rs:231-257,334-353
+//   poly ladder        Polynomial::compress_bounded              atsc/src/compressor/polynomial.rs:209-305,342-373
+//   rle phase          IndexRLE::new + Encode                    atsc/src/compressor/rle.rs:40-67,142-189
+//   selector           CompressorFrame::compress_best            atsc/src/frame/mod.rs:71-149
+//   emitters           bincode Encode impls                      fft.rs:119-130, polynomial.rs:54-87,
+//                                                                constant.rs:37-64, rle.rs:40-67, noop.rs:23-27
+//
+// The FFT ladder does not run 23 inverse FFTs.  The inverse transform of a K-sparse Hermitian
+// spectrum is linear, so each ladder trip only adds the newly admitted bins to a per-sample
+// running sum (2 FMAs per bin and sample, twiddles from the LDS table); the result is the
+// same quantity the reference's inverse FFT produces, up to complex-f32 rounding.
+//
+// No MFMA: there is no dense contraction on this path.  Built with -ffp-contract=off so the
+// f64 spline arithmetic is evaluated exactly as written (Rust never fuses a*b+c).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "atsc_device.h"
+
+namespace atsc {
+
+// --------------------------------------------------------------------------------------------
+// forward transform, complex f32, unnormalised, e^{-i...}  (rustfft plan_fft_forward)
+// Stockham autosort, radices 4/2/3; tw[t] = (cos, sin)(2 pi t / L).
+// Returns the buffer that holds the result.
+// --------------------------------------------------------------------------------------------
+DEVI float2 cmul_conj_tw(float2 v, float2 w)  // v * (w.x - i w.y)
+{
+    return make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+}
+template <int W>
+DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    const uint32_t L = P.L;
+    uint32_t ncur = L, st = 1;
+    for (uint32_t s = 0; s < P.nstages; ++s) {
+        const uint32_t r = P.radix[s];
+        const uint32_t m = ncur / r;
+        const uint32_t nb = L / r;
+        for (uint32_t t = threadIdx.x; t < nb; t += T) {
+            const uint32_t p = t / st, q = t - p * st;
+            const uint32_t ib = q + st * p;        // + st*m*j
+            const uint32_t ob = q + st * (r * p);  // + st*k
+            const uint32_t sm = st * m;
+            const uint32_t tb = p * st;            // twiddle index step per k
+            if (r == 4) {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
+                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+                const float2 t3 = make_float2(d.y, -d.x);  // d * (-i)
+                const float2 b0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+                const float2 b1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+                const float2 b2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+                const float2 b3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+                Y[ob] = b0;
+                Y[ob + st] = cmul_conj_tw(b1, tw[tb]);
+                Y[ob + 2 * st] = cmul_conj_tw(b2, tw[2 * tb]);
+                Y[ob + 3 * st] = cmul_conj_tw(b3, tw[3 * tb]);
+            } else if (r == 2) {
+                const float2 a0 = X[ib], a1 = X[ib + sm];
+                Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(a0.x - a1.x, a0.y - a1.y), tw[tb]);
+            } else {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm];
+                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                const float h = 0.8660254037844386f;
+                const float2 t3 = make_float2(h * d.y, -h * d.x);  // -i * h * d
+                Y[ob] = make_float2(a0.x + t1.x, a0.y + t1.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmul_conj_tw(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = X; X = Y; Y = tmp;
+        ncur = m;
+        st *= r;
+    }
+    return X;
+}
+
+// O(n^2) transform for n < 128 (any n, primes included).  f64 accumulation, f32 result.
+template <int W>
+DEVI void dft_direct(const DevPlan &P, const double *xs, float2 *out, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    const uint32_t n = P.L;
+    for (uint32_t k = threadIdx.x; k < P.bins; k += T) {
+        double re = 0.0, im = 0.0;
+        uint32_t idx = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const double g = (double)(float)xs[j];
+            const float2 w = tw[idx];
+            re += g * (double)w.x;
+            im -= g * (double)w.y;
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        out[k] = make_float2((float)re, (float)im);
+    }
+    __syncthreads();
+}
+
+// --------------------------------------------------------------------------------------------
+// the frame kernel
+// --------------------------------------------------------------------------------------------
+template <int W, int SPL>
+__global__ __launch_bounds__(64 * W) void k_compress(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+    const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag)
+{
+    constexpr int T = 64 * W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t fid = ids[blockIdx.x];
+    const DevFrame fr = frames[fid];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins;
+
+    double *xs = (double *)(smem + P.o_xs);
+    float2 *tw = (float2 *)(smem + P.o_tw);
+    float2 *A = (float2 *)(smem + P.o_a);
+    float2 *B = (float2 *)(smem + P.o_b);
+    Sel *sel = (Sel *)(smem + P.o_sel);
+    uint32_t *aux = (uint32_t *)(smem + P.o_aux);
+    double *red = (double *)(smem + P.o_red);
+    uint32_t *wsum = (uint32_t *)(red + 32);
+    int parity = 0;
+
+    uint8_t *out = slots + fr.slot_off;
+    const int mode = prm.mode;
+
+    // ---- load samples + twiddles ----------------------------------------------------------
+    {
+        const double *src = samples + fr.sample_off;
+        for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
+        const float2 *twp = twpool + P.tw_off;
+        for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
+    }
+    __syncthreads();
+
+    // ---- stats: min/max keep the first occurrence (strict compares, utils.rs:56-63) --------
+    double smin, smax;
+    uint32_t bitdepth;
+    {
+        const double x0 = xs[0];
+        double mn = x0, mx = x0;
+        uint32_t mni = 0, mxi = 0, fr_any = 0;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double v = xs[j];
+            int64_t ip;
+            bool fz;
+            split_n(v, ip, fz);
+            fr_any |= fz ? 1u : 0u;
+            if (v > mx) { mx = v; mxi = j; }
+            if (v < mn) { mn = v; mni = j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+            const uint32_t omni = __shfl_xor(mni, o), omxi = __shfl_xor(mxi, o);
+            if (omn < mn || (omn == mn && omni < mni)) { mn = omn; mni = omni; }
+            if (omx > mx || (omx == mx && omxi < mxi)) { mx = omx; mxi = omxi; }
+            fr_any |= __shfl_xor(fr_any, o);
+        }
+        if (W > 1) {
+            // cross-wave combine through LDS (A is free here)
+            double *rv = (double *)A;
+            uint32_t *ri = (uint32_t *)(rv + 2 * W);
+            if ((tid & 63) == 0) {
+                const uint32_t w = tid >> 6;
+                rv[2 * w] = mn; rv[2 * w + 1] = mx;
+                ri[3 * w] = mni; ri[3 * w + 1] = mxi; ri[3 * w + 2] = fr_any;
+            }
+            __syncthreads();
+            mn = rv[0]; mx = rv[1]; mni = ri[0]; mxi = ri[1]; fr_any = ri[2];
+            for (int w = 1; w < W; ++w) {
+                const double omn = rv[2 * w], omx = rv[2 * w + 1];
+                const uint32_t omni = ri[3 * w], omxi = ri[3 * w + 1];
+                if (omn < mn || (omn == mn && omni < mni)) { mn = omn; mni = omni; }
+                if (omx > mx || (omx == mx && omxi < mxi)) { mx = omx; mxi = omxi; }
+                fr_any |= ri[3 * w + 2];
+            }
+            __syncthreads();
+        }
+        smin = mn; smax = mx;
+        int64_t maxi, mini;
+        bool fz;
+        split_n(smax, maxi, fz);
+        split_n(smin, mini, fz);
+        bitdepth = fr_any ? 0u : bitdepth_of(maxi, mini);
+    }
+
+    atsc_frame_diag dg;
+    dg.fft_size = dg.poly_size = dg.rle_size = 0xFFFFFFFFu;
+    dg.fft_trips = dg.fft_k = dg.poly_trips = dg.poly_step = 0;
+    dg.poly_points = 0;
+    dg.fft_err = dg.poly_err = 0.0;
+
+    // ---- Constant: frame/mod.rs:82-88 (auto shortcut) or forced (constant.rs:135-139) ------
+    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && smin == smax)) {
+        if (tid == 0) {
+            out[0] = 30;
+            out[1] = (uint8_t)bitdepth;
+            const uint32_t vb = put_value(out + 2, bitdepth, smin);
+            res[fid].err = 0.0;
+            res[fid].len = 2 + vb;
+            res[fid].chosen = ATSC_CONSTANT;
+            if (diag) diag[fid] = dg;
+        }
+        return;
+    }
+
+    // ---- Noop: noop.rs:37-43,72-77 ---------------------------------------------------------
+    if (mode == ATSC_NOOP) {
+        for (uint32_t j = tid; j < n; j += T) aux[j] = vlen(zigzag(sat_i64(round(xs[j]))));
+        __syncthreads();
+        const uint32_t tot = block_excl_scan<W>(aux, n, wsum);
+        const uint32_t hdr = 1 + vlen(n);
+        for (uint32_t j = tid; j < n; j += T)
+            put_varint(out + hdr + aux[j], zigzag(sat_i64(round(xs[j]))));
+        if (tid == 0) {
+            out[0] = 250;
+            put_varint(out + 1, n);
+            res[fid].err = 0.0;
+            res[fid].len = hdr + tot;
+            res[fid].chosen = ATSC_NOOP;
+            if (diag) diag[fid] = dg;
+        }
+        return;
+    }
+
+    // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T
+    double g[SPL], inv[SPL];
+#pragma unroll
+    for (int m = 0; m < SPL; ++m) {
+        const uint32_t j = tid + m * T;
+        if (j < L) {
+            int32_t i = (int32_t)j - (int32_t)pre;
+            i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
+            g[m] = xs[i];
+            inv[m] = 1.0 / fabs(g[m]);
+        } else {
+            g[m] = 1.0;
+            inv[m] = 0.0;
+        }
+    }
+
+    // =========================================================================================
+    // FFT candidate: fft.rs:288-362
+    // =========================================================================================
+    const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
+    uint32_t fft_k = 0, fft_size = 0xFFFFFFFFu, fft_trips = 0;
+    double fft_err = 0.0;
+    const float mxf = (float)smax, mnf = (float)smin;
+    if (run_fft) {
+        if (mxf == mnf) {
+            fft_k = 0;  // fft.rs:289-292 ; error None -> 0.0 (fft.rs:523)
+            fft_size = 1 + 1 + 8;
+        } else {
+            float2 *spec;
+            if (P.direct) {
+                dft_direct<W>(P, xs, A, tw);
+                spec = A;
+            } else {
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) A[j] = make_float2((float)g[m], 0.0f);
+                }
+                __syncthreads();
+                spec = fft_forward<W>(P, A, B, tw);
+            }
+            uint64_t *keys = (uint64_t *)(spec == A ? B : A);
+            // fft.rs:88-106 order by f32 norm = hypot(re, im); ties broken by position (ascending)
+            uint32_t nz = 0;
+            for (uint32_t k = tid; k < bins; k += T) {
+                const float2 z = spec[k];
+                const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
+                nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+            }
+            __syncthreads();
+            const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
+            block_sort<W, true>(keys, nullptr, bins, P.p2bins);
+
+            float acc[SPL];
+#pragma unroll
+            for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
+            float dc = 0.0f;
+            const double mxd = (double)mxf, mnd = (double)mnf;
+            const double Ld = (double)L;
+            uint32_t used = 0, jump = 0;
+            double cur = prm.max_err + 1.0;
+            while (prm.max_err_m < sat_i32(cur * 1000.0)) {  // fft.rs:334
+                ++fft_trips;
+                const uint32_t K = min(P.mf + jump, Z);
+                for (; used < K; ++used) {
+                    const uint32_t pos = (uint32_t)(keys[used] & 0xffffffffu);
+                    const float2 z = spec[pos];
+                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once
+                    const double cf = (pos == 0 || 2 * pos == L) ? 1.0 : 2.0;
+                    const float a = (float)(cf * (double)z.x / Ld);
+                    const float b = (float)(cf * (double)z.y / Ld);
+                    if (pos == 0) {
+                        dc = a;
+                    } else {
+                        uint32_t idx = (pos * tid) % L;
+                        const uint32_t stp = (pos * (uint32_t)T) % L;
+#pragma unroll
+                        for (int m = 0; m < SPL; ++m) {
+                            if (tid + m * T < L) {
+                                const float2 w = tw[idx];
+                                acc[m] = fmaf(a, w.x, acc[m]);
+                                acc[m] = fmaf(-b, w.y, acc[m]);
+                            }
+                            idx += stp;
+                            if (idx >= L) idx -= L;
+                        }
+                    }
+                }
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    if (tid + m * T < L) {
+                        const double v = (double)(acc[m] + dc);
+                        double o = round(v * 100000.0) * 1.0e-5;  // fft.rs:208-218
+                        if (o > mxd) o = mxd;
+                        if (o < mnd) o = mnd;
+                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
+                    }
+                }
+                s = block_sum_f64<W>(s, red, parity);
+                cur = s / Ld;
+                if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
+                else if (fft_trips <= 22) jump += P.dk2;
+                else break;
+            }
+            fft_err = cur;
+            fft_k = used;
+            uint32_t big = 0;
+            for (uint32_t i = tid; i < used; i += T) {
+                const uint32_t pos = (uint32_t)(keys[i] & 0xffffffffu);
+                const float2 z = spec[pos];
+                sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
+                big += (pos >= 251) ? 1u : 0u;
+            }
+            __syncthreads();
+            big = block_sum_u32<W>(big, red, parity);
+            fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+        }
+        dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
+        dg.fft_err = fft_err;
+    }
+
+    // =========================================================================================
+    // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
+    // =========================================================================================
+    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
+    uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
+    double poly_err = 0.0;
+    if (run_poly) {
+        if (smax == smin) {
+            poly_K = 0;  // polynomial.rs:210-213
+            poly_step = 1;
+        } else {
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+            double cur = prm.max_err + 1.0;
+            uint32_t jump = 0;
+            while (prm.poly_target < round(cur * 10000.0) / 10000.0) {
+                ++poly_trips;
+                const uint32_t pts = base + jump;
+                const uint32_t step = max(n / pts, 1u);
+                const uint32_t cnt = (n + step - 1) / step;
+                const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                poly_step = step;
+                poly_K = K;
+                if (step > 1) {
+                    const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+                    double s = 0.0;
+#pragma unroll
+                    for (int m = 0; m < SPL; ++m) {
+                        const uint32_t j = tid + m * T;
+                        if (j >= pre && j < pre + n) {
+                            const double sv = spline_eval(
+                                [&](uint32_t k) { return xs[(k == K - 1) ? (n - 1) : k * step]; },
+                                j - pre, n, step, K, magic);
+                            double o = round(sv * 100000.0) * 1.0e-5;  // utils/mod.rs:66-74
+                            if (o < smin) o = smin;
+                            else if (o > smax) o = smax;
+                            s += fabs(o - g[m]) * inv[m];
+                        }
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                }
+                if (poly_trips <= 17) jump += dj1;
+                else if (poly_trips <= 22) jump += dj2;
+                else if (prm.poly_target > round(cur * 10000.0) / 10000.0) break;
+                else { poly_step = 1; poly_K = n; cur = 0.0; break; }
+                if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
+            }
+            poly_err = cur;
+        }
+        // size: polynomial.rs:54-87
+        uint32_t vb = 0;
+        for (uint32_t k = tid; k < poly_K; k += T) {
+            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+            vb += value_bytes(bitdepth, xs[t]);
+        }
+        vb = block_sum_u32<W>(vb, red, parity);
+        poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
+        dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
+        dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
+    }
+
+    // =========================================================================================
+    // RLE candidate: rle.rs:142-189.  Exact size only when it can still win.
+    // =========================================================================================
+    const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
+    uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0;
+    bool rle_sorted = false;
+    uint64_t *rkeys = (uint64_t *)A;            // 8n <= 8L bytes
+    uint32_t *rstart = (uint32_t *)B;           // 4n
+    uint32_t *rends = rstart + n;               // 4n  (later: group head positions hp[])
+    uint32_t *rps = (uint32_t *)tw;             // 4n  prefix of index varint bytes
+    uint32_t *rph = rps + n;                    // 4n  prefix of group header bytes
+    if (run_rle) {
+        const double me = prm.max_err;
+        const bool pf = run_fft && (fft_err <= me), pp = run_poly && (poly_err <= me);
+        uint32_t best_other = 0xFFFFFFFFu;
+        if (pf) best_other = fft_size;
+        if (pp && poly_size < best_other) best_other = poly_size;
+        // run ends: x[j+1] != x[j] (rle.rs:154)
+        for (uint32_t j = tid; j < n; j += T)
+            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t R = block_excl_scan<W>(aux, n, wsum);
+        rle_R = R;
+        for (uint32_t j = tid; j < n; j += T)
+            if (j + 1 >= n || xs[j + 1] != xs[j]) rends[aux[j]] = j;
+        __syncthreads();
+        uint32_t ib = 0;
+        for (uint32_t r = tid; r < R; r += T) {
+            const uint32_t e = rends[r];
+            const uint32_t st = r ? rends[r - 1] + 1 : 0;
+            rkeys[r] = (uint64_t)__double_as_longlong(xs[e]);
+            rstart[r] = st;
+            ib += vlen(st);
+        }
+        __syncthreads();
+        ib = block_sum_u32<W>(ib, red, parity);
+        const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
+        const uint32_t lb = 3 + ib + (R >= 2 ? 2u : 1u) * (minval + 1);
+        if (mode == ATSC_RLE || lb < best_other) {
+            uint32_t p2 = 1;
+            while (p2 < R) p2 <<= 1;
+            block_sort<W, false>(rkeys, rstart, R, p2);
+            rle_sorted = true;
+            for (uint32_t i = tid; i < R; i += T)
+                aux[i] = (i == 0 || rkeys[i] != rkeys[i - 1]) ? 1u : 0u;
+            __syncthreads();
+            const uint32_t D = block_excl_scan<W>(aux, R, wsum);
+            rle_D = D;
+            for (uint32_t i = tid; i < R; i += T)
+                if (i == 0 || rkeys[i] != rkeys[i - 1]) rends[aux[i]] = i;  // hp[g]
+            if (tid == 0) rends[D] = R;
+            __syncthreads();
+            uint32_t hb = 0;
+            for (uint32_t gi = tid; gi < D; gi += T) {
+                const uint32_t h0 = rends[gi], h1 = rends[gi + 1];
+                const uint32_t b = value_bytes(bitdepth, __longlong_as_double((long long)rkeys[h0])) +
+                                   vlen(h1 - h0);
+                rph[gi] = b;
+                hb += b;
+            }
+            __syncthreads();
+            hb = block_sum_u32<W>(hb, red, parity);
+            rle_size = 2 + vlen(D) + hb + ib;
+        } else {
+            rle_size = lb;  // a lower bound that already cannot win
+        }
+        dg.rle_size = rle_sorted ? rle_size : 0xFFFFFFFEu;
+    }
+
+    // =========================================================================================
+    // selection: frame/mod.rs:113-147 (smallest passing payload, first of [FFT, Poly, RLE] on ties)
+    // =========================================================================================
+    int chosen;
+    double chosen_err;
+    if (mode == ATSC_AUTO) {
+        const double me = prm.max_err;
+        const bool pf = fft_err <= me, pp = poly_err <= me;  // RLE reports 0.0 and always passes
+        chosen = ATSC_RLE;
+        uint32_t bs = rle_size;
+        if (pp && poly_size <= bs) { chosen = ATSC_POLYNOMIAL; bs = poly_size; }
+        if (pf && fft_size <= bs) { chosen = ATSC_FFT; bs = fft_size; }
+        chosen_err = chosen == ATSC_FFT ? fft_err : chosen == ATSC_POLYNOMIAL ? poly_err : 0.0;
+    } else {
+        chosen = mode;
+        chosen_err = mode == ATSC_FFT ? fft_err : mode == ATSC_POLYNOMIAL ? poly_err : 0.0;
+    }
+
+    // =========================================================================================
+    // emit the chosen payload into the frame's slot
+    // =========================================================================================
+    uint32_t out_len = 0;
+    if (chosen == ATSC_FFT) {  // fft.rs:119-130
+        const uint32_t hdr = 1 + vlen(fft_k);
+        for (uint32_t i = tid; i < fft_k; i += T) aux[i] = vlen(sel[i].pos) + 8;
+        __syncthreads();
+        const uint32_t body = block_excl_scan<W>(aux, fft_k, wsum);
+        for (uint32_t i = tid; i < fft_k; i += T) {
+            uint8_t *p = out + hdr + aux[i];
+            p += put_varint(p, sel[i].pos & 0xffffu);  // `pos as u16` (fft.rs:242)
+            put_f32(p, sel[i].re);
+            put_f32(p + 4, sel[i].im);
+        }
+        if (tid == 0) {
+            out[0] = 15;
+            put_varint(out + 1, fft_k);
+            put_f32(out + hdr + body, mxf);
+            put_f32(out + hdr + body + 4, mnf);
+        }
+        out_len = hdr + body + 8;
+    } else if (chosen == ATSC_POLYNOMIAL) {  // polynomial.rs:54-87
+        const uint32_t hdr = 2 + vlen(poly_K);
+        for (uint32_t k = tid; k < poly_K; k += T) {
+            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+            aux[k] = value_bytes(bitdepth, xs[t]);
+        }
+        __syncthreads();
+        const uint32_t body = block_excl_scan<W>(aux, poly_K, wsum);
+        for (uint32_t k = tid; k < poly_K; k += T) {
+            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+            put_value(out + hdr + aux[k], bitdepth, xs[t]);
+        }
+        if (tid == 0) {
+            out[0] = 0;  // PolynomialType::Polynomial
+            out[1] = (uint8_t)bitdepth;
+            put_varint(out + 2, poly_K);
+            put_f64(out + hdr + body, smin);
+            put_f64(out + hdr + body + 8, smax);
+            out[hdr + body + 16] = (uint8_t)poly_step;  // `step as u8`
+        }
+        out_len = hdr + body + 17;
+    } else {  // RLE: rle.rs:40-67
+        // records are sorted by (value bits, start); aux[i] = heads before i; rends = hp[]; rph = hb[]
+        const uint32_t R = rle_R, D = rle_D;
+        const uint32_t hdr = 2 + vlen(D);
+        for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rstart[i]);
+        __syncthreads();
+        block_excl_scan<W>(rps, R, wsum);
+        const uint32_t hb = block_excl_scan<W>(rph, D, wsum);
+        uint32_t ibt = 0;
+        for (uint32_t i = tid; i < R; i += T) {
+            const bool head = (i == 0 || rkeys[i] != rkeys[i - 1]);
+            const uint32_t gi = head ? aux[i] : aux[i] - 1;
+            const uint32_t ghb = (gi + 1 < D ? rph[gi + 1] : hb);  // header bytes up to and incl. gi
+            if (head) {
+                uint8_t *p = out + hdr + rph[gi] + rps[i];
+                p += put_value(p, bitdepth, __longlong_as_double((long long)rkeys[i]));
+                put_varint(p, rends[gi + 1] - rends[gi]);
+            }
+            put_varint(out + hdr + ghb + rps[i], rstart[i]);
+            if (i == R - 1) ibt = rps[i] + vlen(rstart[i]);
+        }
+        ibt = block_sum_u32<W>(ibt, red, parity);
+        if (tid == 0) {
+            out[0] = 60;
+            out[1] = (uint8_t)bitdepth;
+            put_varint(out + 2, D);
+        }
+        out_len = hdr + hb + ibt;
+    }
+    if (tid == 0) {
+        res[fid].err = chosen_err;
+        res[fid].len = out_len;
+        res[fid].chosen = (uint32_t)chosen;
+        if (diag) diag[fid] = dg;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// packing: frame records -> contiguous BRO body   (frame/mod.rs:25-33, data.rs:79-85)
+// --------------------------------------------------------------------------------------------
+constexpr int PACK_CHUNK = 1024;  // frames per scan block
+
+DEVI uint32_t rec_header_len(uint32_t n, uint32_t tag, uint32_t len)
+{
+    return 1 /* varint(41) */ + vlen(n) + vlen(tag) + vlen(len);
+}
+
+__global__ __launch_bounds__(256) void k_pack_scan1(const DevFrame *__restrict__ frames,
+                                                    const DevResult *__restrict__ res,
+                                                    uint64_t n_frames, uint32_t *__restrict__ local,
+                                                    uint64_t *__restrict__ blocksum)
+{
+    __shared__ uint32_t sh[PACK_CHUNK];
+    __shared__ uint32_t ws[8];
+    const uint64_t base = (uint64_t)blockIdx.x * PACK_CHUNK;
+    for (uint32_t i = threadIdx.x; i < PACK_CHUNK; i += 256) {
+        const uint64_t f = base + i;
+        uint32_t v = 0;
+        if (f < n_frames) {
+            const DevResult r = res[f];
+            v = rec_header_len(frames[f].n, r.chosen, r.len) + r.len;
+        }
+        sh[i] = v;
+    }
+    __syncthreads();
+    const uint32_t tot = block_excl_scan<4>(sh, PACK_CHUNK, ws);
+    for (uint32_t i = threadIdx.x; i < PACK_CHUNK; i += 256)
+        if (base + i < n_frames) local[base + i] = sh[i];
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the per-chunk totals (u64), in place; total -> blocksum[nb]
+__global__ __launch_bounds__(256) void k_pack_scan2(uint64_t *__restrict__ blocksum, uint32_t nb)
+{
+    __shared__ uint64_t carry;
+    __shared__ uint64_t ws[4];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nb ? blocksum[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t t = __shfl_up(incl, o);
+            if ((threadIdx.x & 63) >= (uint32_t)o) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint64_t add = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) add += ws[w];
+        if (i < nb) blocksum[i] = incl - v + add;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = incl + add;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+
+// one wavefront per frame: header varints + payload copy; also the user-visible side arrays
+__global__ __launch_bounds__(256) void k_pack_emit(
+    const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
+    const uint32_t *__restrict__ local, const uint64_t *__restrict__ blocksum,
+    const uint8_t *__restrict__ slots, uint8_t *__restrict__ body, uint64_t body_cap,
+    uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen, double *__restrict__ err)
+{
+    const uint64_t f = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (f >= n_frames) return;
+    const DevFrame fr = frames[f];
+    const DevResult r = res[f];
+    const uint64_t off = blocksum[f / PACK_CHUNK] + local[f];
+    const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
+    if (lane == 0) {
+        rec_off[f] = off;
+        if (chosen) chosen[f] = (uint8_t)r.chosen;
+        if (err) err[f] = r.err;
+        if (f == n_frames - 1) rec_off[n_frames] = off + hl + r.len;
+    }
+    if (off + hl + r.len > body_cap) return;  // caller sized d_body too small; rec_off tells
+    uint8_t *dst = body + off;
+    if (lane == 0) {
+        uint8_t *p = dst;
+        *p++ = 41;  // frame_size: size_of_val sum, always 41 on 64-bit (frame/mod.rs:50-56)
+        p += put_varint(p, fr.n);
+        p += put_varint(p, r.chosen);
+        p += put_varint(p, r.len);
+    }
+    const uint8_t *src = slots + fr.slot_off;
+    for (uint32_t b = lane; b < r.len; b += 64) dst[hl + b] = src[b];
+}
+
+// --------------------------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------------------------
+template <int W, int SPL>
+static hipError_t launch_class(uint32_t count, uint32_t lds, const double *samples,
+                               const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
+                               const float2 *twpool, const KParams &prm, uint8_t *slots,
+                               DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    auto kern = k_compress<W, SPL>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, samples, frames, ids, plans, twpool,
+                       prm, slots, res, diag);
+    return hipGetLastError();
+}
+
+hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
+                                 const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
+                                 const float2 *twpool, const KParams &prm, uint8_t *slots,
+                                 DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+{
+    switch (cls) {
+    case 0: return launch_class<1, 2>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
+                       uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
+                       uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
+                       hipStream_t s)
+{
+    const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
+    hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
+                       blocksum);
+    hipLaunchKernelGGL(k_pack_scan2, dim3(1), dim3(256), 0, s, blocksum, nb);
+    hipLaunchKernelGGL(k_pack_emit, dim3((uint32_t)((n_frames + 3) / 4)), dim3(256), 0, s, frames,
+                       res, n_frames, local, blocksum, slots, body, body_cap, rec_off, chosen, err);
+    return hipGetLastError();
+}
+
+}  // namespace atsc

@@ -1,0 +1,180 @@
+/*
+ * atsc_hip.h -- C ABI of the MI355X-native ATSC compression core (libatsc_hip.so).
+ *
+ * This is the drop-in boundary for the per-frame compressor path of
+ * instaclustr/atsc.  The reference has no FFI of its own (it is a single Rust
+ * process); the seam a replacement must honour is the Rust API both CLIs call:
+ *     CompressedStream::{compress_chunk_with, compress_chunk_bounded_with,
+ *                        to_bytes, from_bytes, decompress}   atsc/src/data.rs:47-109
+ *     OptimizerPlan::{plan, get_execution}                   atsc/src/optimizer/mod.rs:47-109
+ * The reference compresses one chunk per call; a GPU wants a batch, so the ABI
+ * takes the whole chunk list ("frames") of one or many series at once.  Frame
+ * semantics (codec choice, payload bytes, error bound) are per frame and equal
+ * the reference's.  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add and where it replaces the loop at atsc/src/main.rs:146-163.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative ATSC_E_* code and never aborts/throws across the ABI
+ * (the reference panics instead: data.rs:98, header.rs:34-37,72-74).
+ * The caller owns every buffer it passes; the library owns device scratch.
+ * One atsc_ctx per host thread (mirrors `&mut self`).  `*_dev` entry points
+ * take DEVICE pointers and a hipStream_t (as void*), enqueue work and return
+ * without synchronising; the others take HOST pointers and are synchronous.
+ *
+ * All citations are relative to the reference repository root.
+ */
+#ifndef ATSC_HIP_H
+#define ATSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Compressor wire ids == enum Compressor discriminants, atsc/src/compressor/mod.rs:35-44 */
+enum {
+    ATSC_NOOP = 0,
+    ATSC_FFT = 1,
+    ATSC_IDW = 2,
+    ATSC_CONSTANT = 3,
+    ATSC_POLYNOMIAL = 4,
+    ATSC_AUTO = 5,
+    ATSC_RLE = 6
+};
+
+enum {
+    ATSC_OK = 0,
+    ATSC_E_INVALID = -1,      /* bad argument (null pointer, empty frame, bad level) */
+    ATSC_E_NOMEM = -2,        /* host or device allocation failed */
+    ATSC_E_UNSUPPORTED = -3,  /* valid in the reference, not implemented here (see atsc_strerror) */
+    ATSC_E_NO_DEVICE = -4,    /* no usable HIP device; the library never falls back to a CPU path */
+    ATSC_E_HIP = -5,          /* a HIP runtime call failed; see atsc_ctx_last_error */
+    ATSC_E_CAPACITY = -6,     /* caller buffer too small */
+    ATSC_E_FORMAT = -7,       /* malformed BRO / WBRO / CSV bytes (reference: panic / Err) */
+    ATSC_E_VERSION = -8,      /* BRO version newer than 1 (header.rs:30-42) */
+    ATSC_E_IO = -9            /* file could not be read / written */
+};
+
+typedef struct atsc_ctx atsc_ctx;
+typedef struct atsc_plan atsc_plan;
+typedef struct atsc_dplan atsc_dplan;
+typedef struct atsc_stream atsc_stream;
+
+const char *atsc_strerror(int rc);
+const char *atsc_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* context                                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device` (0-based).  Fails with
+ * ATSC_E_NO_DEVICE when there is no GPU: there is no CPU fallback. */
+int atsc_ctx_create(atsc_ctx **out, int device);
+void atsc_ctx_destroy(atsc_ctx *ctx);
+const char *atsc_ctx_last_error(const atsc_ctx *ctx);
+
+/* ------------------------------------------------------------------------ */
+/* compress: CompressorFrame::{compress, compress_bounded, compress_best}    */
+/*           atsc/src/frame/mod.rs:59-149 over a batch of frames             */
+/* ------------------------------------------------------------------------ */
+
+/* Frame layout of one batch.  frame_off[n_frames+1] are prefix offsets (in
+ * samples) into the sample array: frame i = samples[frame_off[i] .. frame_off[i+1]).
+ * Replaces the chunk list of OptimizerPlan::get_execution (optimizer/mod.rs:101-109). */
+int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64_t n_frames,
+                     atsc_plan **out);
+void atsc_plan_destroy(atsc_plan *plan);
+uint64_t atsc_plan_n_frames(const atsc_plan *plan);
+uint64_t atsc_plan_n_samples(const atsc_plan *plan);
+/* Worst-case bytes of the encoded frame records of this plan (size d_body with it). */
+uint64_t atsc_plan_body_bound(const atsc_plan *plan);
+/* Worst-case payload bytes of one frame of n samples (RLE, all values distinct). */
+uint64_t atsc_payload_bound_bytes(uint64_t n_samples_in_frame);
+
+/* Compresses every frame of `plan` on the GPU.
+ *   compressor   ATSC_* id.  ATSC_AUTO = compress_best (frame/mod.rs:71-149).
+ *   bounded      1 = compress_chunk_bounded_with (data.rs:56-76), 0 = compress_chunk_with
+ *                (data.rs:47-53).  The atsc CLI uses bounded for fft/polynomial/idw/auto and
+ *                unbounded for noop/constant/rle (main.rs:150-162).
+ *   max_error    the f32 the reference passes: `e as f32 / 100.0` (main.rs:157)
+ *   sample_level 0..6, index into COMPRESSION_SPEED (frame/mod.rs:22); only used by ATSC_AUTO
+ * Outputs (device memory):
+ *   d_body       encoded frame records in frame order, each exactly the bincode image of
+ *                CompressorFrame (frame/mod.rs:25-33): varint(41) varint(sample_count)
+ *                varint(compressor) varint(len) payload.  A .bro file is
+ *                "BRRO" u32le(1) u8(n_frames) varint(n_frames) followed by these bytes
+ *                (header.rs:60-67, data.rs:79-85); see atsc_bro_wrap.
+ *   d_rec_off    n_frames+1 byte offsets of the records in d_body; [n_frames] = total bytes
+ *   d_chosen     n_frames, compressor id actually used (may be NULL)
+ *   d_err        n_frames, CompressorResult.error of the chosen codec (may be NULL)
+ * Nothing is synchronised; the work is enqueued on `stream`. */
+int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
+                           int compressor, int bounded, float max_error, int sample_level,
+                           uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
+                           uint8_t *d_chosen, double *d_err, void *stream);
+
+/* Per-frame diagnostics of the last atsc_compress_plan_dev on this ctx (host copy,
+ * synchronises the stream).  One record per frame; used by the parity tests. */
+typedef struct {
+    uint32_t fft_size, poly_size, rle_size; /* candidate payload bytes; 0xFFFFFFFF = not run */
+    uint16_t fft_trips, fft_k;              /* ladder trips (fft.rs:334-353), stored bins */
+    uint16_t poly_trips, poly_step;         /* ladder trips (polynomial.rs:231-270), point_step */
+    uint32_t poly_points;
+    double fft_err, poly_err;
+} atsc_frame_diag;
+/* Diagnostics cost 40 B/frame of HBM writes, so they are off unless enabled here (or ATSC_DIAG is set). */
+int atsc_ctx_enable_diag(atsc_ctx *ctx, int on);
+int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t n_frames);
+
+/* Host-pointer convenience: plan + H2D + compress + D2H, synchronous.
+ * body_len receives the number of bytes written to `body`. */
+int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                         uint64_t n_frames, int compressor, int bounded, float max_error,
+                         int sample_level, uint8_t *body, uint64_t body_cap, uint64_t *body_len,
+                         uint64_t *rec_off, uint8_t *chosen, double *err);
+
+/* ------------------------------------------------------------------------ */
+/* decompress: CompressedStream::decompress (data.rs:104-109) ->             */
+/*             CompressorFrame::decompress (frame/mod.rs:152-158)            */
+/* ------------------------------------------------------------------------ */
+
+/* Parses frame records (host bytes, as produced above, without the leading
+ * varint(n_frames) unless has_count != 0) and builds the per-frame table. */
+int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
+                      atsc_dplan **out);
+void atsc_dplan_destroy(atsc_dplan *dp);
+uint64_t atsc_dplan_n_frames(const atsc_dplan *dp);
+uint64_t atsc_dplan_n_samples(const atsc_dplan *dp);
+/* d_body: the same bytes on the device; d_out: atsc_dplan_n_samples doubles. */
+int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t *d_body,
+                             double *d_out, void *stream);
+/* Host-pointer convenience (synchronous). out_n receives the sample count. */
+int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
+                           double *out, uint64_t out_cap, uint64_t *out_n);
+
+/* ------------------------------------------------------------------------ */
+/* host-side format helpers (no GPU needed)                                 */
+/* ------------------------------------------------------------------------ */
+
+/* OptimizerPlan::get_chunks_sizes, optimizer/mod.rs:78-98.  Returns the chunk count;
+ * writes at most cap sizes. */
+uint64_t atsc_chunk_sizes(uint64_t len, uint64_t *out, uint64_t cap);
+/* OptimizerPlan::clean_data, optimizer/mod.rs:64-71 (drops NaN and +-Inf). Returns kept count. */
+uint64_t atsc_clean_data(const double *in, uint64_t n, double *out);
+/* utils::next_size, utils/mod.rs:32-38 */
+uint64_t atsc_next_size(uint64_t n);
+/* CompressorHeader::to_bytes + frame count varint (header.rs:60-67, data.rs:83):
+ * writes "BRRO" u32le(1) u8(n_frames mod 256) varint(n_frames) into out (>= 18 bytes);
+ * returns bytes written. */
+uint64_t atsc_bro_prefix(uint64_t n_frames, uint8_t *out);
+/* CompressedStream::from_bytes front half (data.rs:89-97, header.rs:69-84): validates magic
+ * and version; returns the offset of the first frame record (after the count varint) and
+ * the frame count, or ATSC_E_FORMAT / ATSC_E_VERSION. */
+int atsc_bro_open(const uint8_t *bro, uint64_t len, uint64_t *body_off, uint64_t *n_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+"""Frame-by-frame comparison of the HIP path (through the C ABI) with the CPU oracle.
+
+Bars (north_star / SURVEY 8):
+  * Constant / Noop / RLE / Polynomial payloads: byte-identical (integer, byte and f64 index work).
+  * FFT payloads: complex-f32 arithmetic that is not bit-reproducible even between two CPUs
+    running the reference (rustfft picks its SIMD path at run time).  Same ladder trip count,
+    same number of stored bins, same bin positions in the same order, coefficients within
+    FFT_COEF_RTOL of the frame's largest bin, reported error within FFT_ERR_ATOL.
+  * A frame whose oracle error sits within BOUNDARY_EPS of a ladder/selector threshold may
+    legitimately stop one trip apart (f32 noise crossing the threshold); such frames are
+    counted separately and must be rare (< BOUNDARY_FRAC of the batch).
+"""
+import numpy as np
+
+from tests import helpers as H
+
+FFT_COEF_RTOL = 4e-6     # relative to the largest |bin| of the frame (~32 f32 ulp)
+FFT_ERR_ATOL = 2e-6      # absolute, on MAPE
+POLY_ERR_RTOL = 1e-11    # summation order only
+BOUNDARY_EPS = 5e-6
+BOUNDARY_FRAC = 0.002
+
+
+def _near_threshold(err, max_error):
+    """True when err is within BOUNDARY_EPS of a value where the reference's decisions flip:
+    the FFT loop exit trunc(err*1000) (fft.rs:334), the poly exit round(err,4) vs round(max,3)
+    (polynomial.rs:230-231) or the selector's exact filter err <= max_error (frame/mod.rs:128)."""
+    if not np.isfinite(err):
+        return False
+    me = float(np.float32(max_error))
+    cands = [me, np.floor(me * 1000.0 + 1) / 1000.0, round(me, 3) + 0.00005]
+    return any(abs(err - c) < BOUNDARY_EPS for c in cands)
+
+
+def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, report, idx,
+                  oracle_errs=None):
+    """Returns 'exact' | 'tol' | 'boundary' | 'FAIL:<why>'."""
+    if tag != chosen_o:
+        errs = oracle_errs or {}
+        if any(_near_threshold(e, max_error) for e in errs.values()):
+            return "boundary"
+        return "FAIL:codec gpu=%d oracle=%d" % (tag, chosen_o)
+    if payload == payload_o:
+        return "exact"
+    if tag != oracle.FFT:
+        return "FAIL:bytes differ for codec %d (len %d vs %d)" % (tag, len(payload), len(payload_o))
+    fg, mxg, mng = H.parse_fft_payload(payload)
+    fo, mxo, mno = H.parse_fft_payload(payload_o)
+    if (mxg, mng) != (mxo, mno):
+        return "FAIL:fft min/max"
+    if len(fg) != len(fo):
+        errs = oracle_errs or {}
+        if any(_near_threshold(e, max_error) for e in errs.values()):
+            return "boundary"
+        return "FAIL:fft K gpu=%d oracle=%d" % (len(fg), len(fo))
+    scale = max(np.hypot(r, i) for _, r, i in fo) if fo else 1.0
+    pos_g = [f[0] for f in fg]
+    pos_o = [f[0] for f in fo]
+    if pos_g != pos_o:
+        # near-equal norms may swap order; accept only if the multisets agree and the swapped
+        # bins' norms are within tolerance of each other
+        if sorted(pos_g) != sorted(pos_o):
+            # last admitted bin may differ when two norms tie at the cut
+            ng = {p: np.hypot(r, i) for p, r, i in fg}
+            no = {p: np.hypot(r, i) for p, r, i in fo}
+            diff = set(pos_g) ^ set(pos_o)
+            norms = [ng.get(p, no.get(p)) for p in diff]
+            if max(norms) - min(norms) > FFT_COEF_RTOL * scale:
+                return "FAIL:fft bin set differs %s" % sorted(diff)
+            return "tol"
+        dg = {p: (r, i) for p, r, i in fg}
+        for a, b in zip(pos_g, pos_o):
+            if a != b:
+                na, nb = np.hypot(*dg[a]), np.hypot(*dg[b])
+                if abs(na - nb) > FFT_COEF_RTOL * scale:
+                    return "FAIL:fft order"
+    dg = {p: (r, i) for p, r, i in fg}
+    for p, r, i in fo:
+        if p in dg:
+            rg, ig = dg[p]
+            if abs(rg - r) > FFT_COEF_RTOL * scale or abs(ig - i) > FFT_COEF_RTOL * scale:
+                return "FAIL:fft coef pos=%d gpu=(%r,%r) oracle=(%r,%r) scale=%r" % (
+                    p, rg, ig, r, i, scale)
+    return "tol"
+
+
+def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, want_diag=True):
+    """Runs the batch through the C ABI and the oracle; returns a summary dict."""
+    import atsc_amd
+
+    me = float(np.float32(max_error))
+    if want_diag:
+        ctx.enable_diag(True)
+    rec, rec_off, chosen, err = ctx.compress_host(x, off, compressor, bounded, me, level)
+    frames = H.parse_bro_body(rec, with_count=False)
+    nf = len(off) - 1
+    assert len(frames) == nf
+    assert int(rec_off[-1]) == len(rec)
+    summary = {"exact": 0, "tol": 0, "boundary": 0, "fail": [], "codecs": {}, "bytes": len(rec),
+               "oracle_bytes": 0, "records": rec, "chosen": chosen, "err": err}
+    for i, (fs, sc, tag, payload) in enumerate(frames):
+        fx = x[int(off[i]):int(off[i + 1])]
+        assert fs == 41 and sc == len(fx)
+        assert tag == chosen[i]
+        errs = {}
+        if compressor == atsc_amd.AUTO:
+            po, cho, eo = oracle.compress_best(fx, me, level)
+            if True:
+                _, errs["fft"], _ = oracle.fft_allowed_error(fx, me)
+                _, errs["poly"], _ = oracle.polynomial_allowed_error(fx, me)
+        else:
+            po, eo = oracle.compress(compressor, fx, bounded, me)
+            cho = compressor
+            errs["e"] = eo
+        summary["oracle_bytes"] += len(po) + 1 + len(H_varint(len(fx))) + 1 + len(H_varint(len(po)))
+        verdict = compare_frame(oracle, fx, me, tag, payload, cho, po, summary, i, errs)
+        summary["codecs"][tag] = summary["codecs"].get(tag, 0) + 1
+        if verdict.startswith("FAIL"):
+            summary["fail"].append((i, verdict))
+        else:
+            summary[verdict] += 1
+            if verdict != "boundary":
+                # reported error: exact codecs report 0.0; lossy within tolerance
+                tol = FFT_ERR_ATOL if tag == oracle.FFT else max(POLY_ERR_RTOL * abs(eo), 1e-300)
+                if not (abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
+                    summary["fail"].append((i, "FAIL:err gpu=%r oracle=%r" % (err[i], eo)))
+    return summary
+
+
+def H_varint(v):
+    if v < 251:
+        return bytes([v])
+    if v < 65536:
+        return bytes([251]) + int(v).to_bytes(2, "little")
+    if v < 2 ** 32:
+        return bytes([252]) + int(v).to_bytes(4, "little")
+    return bytes([253]) + int(v).to_bytes(8, "little")
+
+
+def assert_summary(summary, nf, what=""):
+    msg = "%s: %d frames exact=%d tol=%d boundary=%d fail=%d %s" % (
+        what, nf, summary["exact"], summary["tol"], summary["boundary"], len(summary["fail"]),
+        summary["fail"][:8])
+    assert not summary["fail"], msg
+    assert summary["boundary"] <= max(1, int(BOUNDARY_FRAC * nf)), msg
+    return msg

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI in include/atsc_hip.h) against the CPU
+oracle on the same seeded inputs, the reference's fixtures, and -- at BASELINE.json's full
+sizes -- size-independent properties (round trips, error bound, stream structure)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+
+ME5 = float(np.float32(5) / np.float32(100))
+ME1 = float(np.float32(1) / np.float32(100))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    import __graft_entry__ as G
+
+    G.build()
+    import atsc_amd
+
+    c = atsc_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def A():
+    import atsc_amd
+
+    return atsc_amd
+
+
+def _log(msg):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity.log", "a") as f:
+        f.write(msg + "\n")
+
+
+# ---------------------------------------------------------------------------------------
+# auto selector on the synthetic classes of SURVEY 8(d), F256 framing (configs[1], configs[2])
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("klass", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("me", [ME5, ME1])
+def test_auto_f256_classes(ctx, A, oracle, klass, me):
+    nfr = 96
+    x = H.synth_series(3, 256 * nfr, klass=klass)
+    off = H.frame_offsets(len(x), 256)
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, me)
+    _log(P.assert_summary(s, nfr, "auto f256 class %d me %.3f codecs %s" % (klass, me, s["codecs"])))
+
+
+def test_auto_mixed_block(ctx, A, oracle):
+    # classes cycled per 1024-sample block so one launch sees every selector branch
+    x = H.synth_series(11, 256 * 200, block=1024)
+    off = H.frame_offsets(len(x), 256)
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME5)
+    assert len(s["codecs"]) >= 4, s["codecs"]
+    _log(P.assert_summary(s, 200, "auto mixed codecs %s" % s["codecs"]))
+    # compression ratio within +-5 % of the oracle on identical framing
+    assert abs(s["bytes"] - s["oracle_bytes"]) <= 0.05 * s["oracle_bytes"]
+
+
+@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "RLE", "CONSTANT", "NOOP"])
+def test_forced_codecs(ctx, A, oracle, comp):
+    cid = getattr(A, comp)
+    bounded = comp in ("FFT", "POLYNOMIAL")  # main.rs:150-162
+    x = np.concatenate([H.synth_series(5, 256 * 12, klass=k) for k in range(5)])
+    off = H.frame_offsets(len(x), 256)
+    s = P.compare_batch(oracle, ctx, x, off, cid, bounded, ME5)
+    _log(P.assert_summary(s, len(off) - 1, "forced %s" % comp))
+    if comp != "FFT":
+        assert s["tol"] == 0 and s["boundary"] == 0
+
+
+# ---------------------------------------------------------------------------------------
+# frame lengths: tails, primes, every kernel class
+# ---------------------------------------------------------------------------------------
+SIZES = [1, 2, 3, 5, 17, 64, 100, 127, 128, 129, 200, 255, 256, 300, 393, 511, 512, 513, 1000, 1024,
+         1500, 2048, 3000, 4096]
+
+
+@pytest.mark.parametrize("klass", [0, 2, 3])
+def test_auto_frame_lengths(ctx, A, oracle, klass):
+    xs, offs = [], [0]
+    for n in SIZES:
+        xs.append(H.synth_series(100 + n, n, klass=klass))
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, ME5)
+    _log(P.assert_summary(s, len(SIZES), "auto lengths class %d codecs %s" % (klass, s["codecs"])))
+
+
+def test_reference_chunker_on_fixture(ctx, A, oracle, golden_dir):
+    # e2e.rs flow on go_gc_heap_goal_bytes.wbro: clean -> chunk (2048, 512, 393) -> auto
+    d = H.read_wbro(os.path.join(golden_dir, "wbros", "go_gc_heap_goal_bytes.wbro"))
+    d = A.clean_data(d)
+    sizes = A.chunk_sizes(len(d))
+    assert sizes == [2048, 512, 393]
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    for e in (0, 1, 3, 5):
+        me = float(np.float32(e) / np.float32(100))
+        s = P.compare_batch(oracle, ctx, d, off, A.AUTO, True, me)
+        _log(P.assert_summary(s, 3, "fixture heap e=%d codecs %s" % (e, s["codecs"])))
+        bro = A.bro_prefix(3) + s["records"]
+        if s["boundary"] == 0 and s["tol"] == 0:
+            assert bro == oracle.compress_data(d, oracle.AUTO, cli_error=e)
+        out = ctx.decompress_host(s["records"])
+        assert len(out) == len(d)
+        if e == 0:
+            assert np.array_equal(out, d)  # e2e.rs:158-160
+        else:
+            assert H.mape(d, out) <= me + 1e-3  # e2e.rs:234-248 (+ fft.rs:334 truncation)
+
+
+def test_csv_constant_kat(ctx, A, oracle, golden_dir):
+    # BASELINE.json configs[0]; hand-derived 58-byte stream of SURVEY 8(c)
+    from tests.golden import kat as K
+
+    vals = H.read_csv_values(os.path.join(golden_dir, "csv", "cpu_utilization.csv"))
+    sizes = A.chunk_sizes(len(vals))
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    rec, _, chosen, _ = ctx.compress_host(vals, off, A.CONSTANT, False, 0.0, 0)
+    assert (A.bro_prefix(len(sizes)) + rec).hex() == K.CSV_CONSTANT_BRO_HEX
+    out = ctx.decompress_host(rec)
+    assert out[0] == 13.85002983491348 and len(out) == 2854
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases the reference's behaviour depends on (D7, D9, D10; App. C)
+# ---------------------------------------------------------------------------------------
+def _edge_frames():
+    rng = np.random.default_rng(42)
+    fr = []
+    fr.append(np.zeros(256))                                   # all zero -> constant
+    z = H.synth_series(1, 256, klass=0); z[17] = 0.0; fr.append(z)   # a zero poisons MAPE (D10)
+    z = H.synth_series(1, 256, klass=0); z[0] = 0.0; fr.append(z)
+    fr.append(-H.synth_series(2, 256, klass=0))                # negative F64
+    fr.append(-np.floor(H.synth_series(2, 256, klass=2)))      # negative integers -> I16
+    fr.append(np.floor(H.synth_series(2, 256, klass=2)) * 100)  # I32 range
+    fr.append(np.floor(H.synth_series(2, 256, klass=2)) * 1e7)  # beyond i32 -> F64 bitdepth
+    fr.append(np.where(np.arange(256) % 2 == 0, 5.0, 250.0))   # alternating two values: RLE R = n
+    fr.append(np.repeat(rng.integers(0, 255, 16), 16).astype(np.float64))  # U8 runs
+    fr.append(rng.integers(0, 255, 256).astype(np.float64))    # U8 noise
+    fr.append(rng.normal(0, 1, 256))                           # sign changes, tiny magnitudes
+    fr.append(np.full(256, 1.23456))                           # F64 constant
+    a = np.full(256, 7.0); a[255] = 8.0; fr.append(a)          # step at the end
+    a = np.full(256, 7.0); a[0] = 8.0; fr.append(a)
+    a = np.full(256, 1e-3); a[100:] = 2e-3; fr.append(a)
+    a = np.full(256, 1000.0); a[::2] += 1e-4; fr.append(a)    # min != max in f64, equal in f32
+    a = np.arange(256, dtype=np.float64); a[0] = -0.0; fr.append(a)
+    fr.append(np.arange(256, dtype=np.float64) + 0.5)
+    fr.append(1e12 + np.arange(256, dtype=np.float64) * 1e6)
+    fr.append(H.synth_series(9, 256, klass=1) * 1e-6)
+    return fr
+
+
+def test_edge_frames_auto(ctx, A, oracle):
+    fr = _edge_frames()
+    x = np.concatenate(fr)
+    off = H.frame_offsets(len(x), 256)
+    for me in (ME5, ME1, 0.0):
+        s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, me)
+        _log(P.assert_summary(s, len(fr), "edge frames me=%r codecs %s" % (me, s["codecs"])))
+
+
+@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "RLE", "NOOP", "CONSTANT"])
+def test_edge_frames_forced(ctx, A, oracle, comp):
+    fr = _edge_frames()
+    x = np.concatenate(fr)
+    off = H.frame_offsets(len(x), 256)
+    s = P.compare_batch(oracle, ctx, x, off, getattr(A, comp), comp in ("FFT", "POLYNOMIAL"), ME5)
+    _log(P.assert_summary(s, len(fr), "edge forced %s" % comp))
+
+
+# ---------------------------------------------------------------------------------------
+# decompression parity (configs[4] path)
+# ---------------------------------------------------------------------------------------
+def test_decompress_matches_oracle(ctx, A, oracle):
+    x = np.concatenate([H.synth_series(21, 256 * 16, klass=k) for k in range(5)] + _edge_frames())
+    off = H.frame_offsets(len(x), 256)
+    nf = len(off) - 1
+    for comp, bounded in ((A.AUTO, True), (A.FFT, True), (A.POLYNOMIAL, True), (A.RLE, False),
+                          (A.NOOP, False), (A.CONSTANT, False)):
+        # decode the ORACLE's stream on the GPU and compare with the oracle's own decode
+        bro, chosen, _ = oracle.stream_compress(x, off, comp, bounded, ME5, 0)
+        ref = oracle.decompress_data(bro)
+        body_off, nfr = A.bro_open(bro)
+        assert nfr == nf
+        out = ctx.decompress_host(bro[body_off:])
+        assert len(out) == len(ref)
+        for i in range(nf):
+            seg = slice(int(off[i]), int(off[i + 1]))
+            if chosen[i] == oracle.FFT:
+                # f32 inverse transform: within 4 f32 ulp of the frame's magnitude (+ 1e-5 grid)
+                scale = max(np.max(np.abs(ref[seg])), 1e-30)
+                assert np.max(np.abs(out[seg] - ref[seg])) <= 4 * scale * 2.0 ** -23 + 1.00001e-5, (
+                    comp, i, np.max(np.abs(out[seg] - ref[seg])))
+            else:
+                assert np.array_equal(out[seg], ref[seg]), (comp, i, chosen[i])
+
+
+def test_decompress_rejects_garbage(ctx, A):
+    with pytest.raises(A.AtscError):
+        ctx.decompress_host(bytes([41, 251, 0, 1, 1, 4, 15, 200, 0, 0]))
+    with pytest.raises(A.AtscError):
+        A.bro_open(b"XXXX" + bytes(10))
+    with pytest.raises(A.AtscError):
+        A.bro_open(b"BRRO" + bytes([9, 0, 0, 0, 1, 1]))
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json full sizes: properties that do not need the oracle
+# ---------------------------------------------------------------------------------------
+def _full_size_roundtrip(ctx, A, n_samples, me, seed):
+    import torch
+
+    x = H.synth_series(seed, n_samples)  # classes cycled per 65536-sample block
+    off = H.frame_offsets(n_samples, 256)
+    nf = len(off) - 1
+    dev = torch.device("cuda:0")
+    plan = ctx.plan(off)
+    d_x = torch.from_numpy(x).to(dev)
+    outs = plan.alloc_outputs(torch, dev)
+    plan.compress(d_x, outs, A.AUTO, True, me, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec_off = outs["rec_off"].cpu().numpy().astype(np.int64)
+    total = int(rec_off[-1])
+    assert np.all(np.diff(rec_off) > 0) and total <= plan.body_bound
+    body = outs["body"][:total].cpu().numpy().tobytes()
+    chosen = outs["chosen"].cpu().numpy()
+    err = outs["err"].cpu().numpy()
+    # determinism: a second run produces the same bytes
+    plan.compress(d_x, outs, A.AUTO, True, me, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert outs["body"][:total].cpu().numpy().tobytes() == body
+    # device-resident decompress
+    dp = A.DPlan(ctx, body)
+    assert dp.n_frames == nf and dp.n_samples == n_samples
+    d_body = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(dev)
+    d_out = torch.empty(n_samples, dtype=torch.float64, device=dev)
+    dp.decompress(d_body, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    xo = x.reshape(nf, 256)
+    oo = out.reshape(nf, 256)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fm = np.sum(np.abs((oo - xo) / xo), axis=1) / 256.0
+    lossless = np.isin(chosen, [A.CONSTANT, A.RLE])
+    assert np.array_equal(oo[lossless], xo[lossless])
+    # every lossy frame honours the bound the selector applied (err <= max_error exactly) and the
+    # decoded error equals the reported one up to f32 reconstruction noise
+    lossy = ~lossless
+    assert np.all(err[lossy] <= me)
+    # Polynomial: the decoder repeats the encoder's arithmetic, so the decoded MAPE is the reported one
+    poly = chosen == A.POLYNOMIAL
+    assert np.all(np.abs(fm[poly] - err[poly]) <= 1e-9)
+    # FFT: the reported error is over the Gibbs-padded signal of L = 288 samples (fft.rs:345); over
+    # the 256 real samples it is at most L/n times that
+    fft = chosen == A.FFT
+    assert np.all(fm[fft] <= me * 288.0 / 256.0 + 2e-6)
+    return {"ratio": 8.0 * n_samples / (total + 10), "codecs": {int(c): int(np.sum(chosen == c))
+                                                                 for c in np.unique(chosen)}}
+
+
+def test_full_size_config1_1m(ctx, A):
+    r = _full_size_roundtrip(ctx, A, 1 << 20, ME5, seed=0)
+    _log("config 1M roundtrip %r" % r)
+
+
+def test_full_size_config2_10m(ctx, A):
+    r = _full_size_roundtrip(ctx, A, 10485760, ME5, seed=0)
+    _log("config 10M roundtrip %r" % r)
+    assert len(r["codecs"]) >= 4
