@@ -55,6 +55,8 @@ SIGNATURES = {
                                          _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "atsc_ctx_enable_diag": (C.c_int, [_vp, C.c_int]),
     "atsc_ctx_last_diag": (C.c_int, [_vp, C.POINTER(FrameDiag), C.c_uint64]),
+    "atsc_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "atsc_ctx_profile_read": (C.c_int, [_vp, _f64p, _u64p]),
     "atsc_compress_frames": (C.c_int, [_vp, _f64p, _u64p, C.c_uint64, C.c_int, C.c_int, C.c_float,
                                        C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u8p, _f64p]),
     "atsc_dplan_create": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, C.POINTER(_vp)]),

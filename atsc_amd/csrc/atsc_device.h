@@ -246,7 +246,7 @@ DEVI double spline_eval(KnotFn V, uint32_t i, uint32_t n, uint32_t step, uint32_
 {
     // V(k): value of knot k;  knot k sits at x = k*step, the last one (k = K-1) at x = n-1
     if (i == n - 1) return V(K - 1);
-    uint32_t seg = __umulhi(i, magic);  // i / step
+    uint32_t seg = (step == 1) ? i : __umulhi(i, magic);  // i / step (magic = 2^32/step + 1, step >= 2)
     if (seg > K - 2) seg = K - 2;
     const uint32_t t0i = seg * step;
     const uint32_t t1i = (seg + 1 == K - 1) ? (n - 1) : (seg + 1) * step;
@@ -269,6 +269,17 @@ DEVI double spline_eval(KnotFn V, uint32_t i, uint32_t n, uint32_t step, uint32_
                m1 * (t3 - t2);
     }
     return v0 * (1.0 - nt) + v1 * nt;
+}
+
+// r / 100000.0 for the 5-decimal rounding (utils/mod.rs:61-74, fft.rs:208-218), correctly rounded
+// without the ~30-instruction IEEE divide: q = r*y, one FMA residual correction (Markstein).
+// Checked against r / 100000.0 for every integer |r| <= 2^27 and 4e8 random integers up to 2^53.
+DEVI double div1e5(double r)
+{
+    const double y = 1.0e-5;
+    const double q = r * y;
+    const double rem = fma(-q, 100000.0, r);
+    return fma(rem, y, q);
 }
 
 struct Sel {

@@ -45,6 +45,10 @@ struct atsc_ctx {
     uint64_t diag_n = 0;
     hipStream_t diag_stream = nullptr;
     bool want_diag = false;
+    // optional timing of the dominant k_compress launch (HIP events on the launch stream)
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
 };
 
 struct PlanTables {
@@ -256,12 +260,37 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
 extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
 {
     if (!ctx) return;
+    for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     delete ctx;
 }
 extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
 {
     return ctx ? ctx->last_error.c_str() : "";
+}
+// Timing of the dominant compress kernel: one event pair per atsc_compress_plan_dev call around
+// the launch of the frame class that holds the most frames.
+extern "C" int atsc_ctx_set_profiling(atsc_ctx *ctx, int on)
+{
+    if (!ctx) return ATSC_E_INVALID;
+    ctx->profiling = on != 0;
+    ctx->ev_used = 0;
+    return ATSC_OK;
+}
+extern "C" int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *launches)
+{
+    if (!ctx || !total_ms || !launches) return ATSC_E_INVALID;
+    double tot = 0.0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[i].second));
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = ctx->ev_used;
+    ctx->ev_used = 0;
+    return ATSC_OK;
 }
 // Diagnostics are opt-in (they add 40 B/frame of HBM writes): enabled by this call.
 extern "C" int atsc_ctx_enable_diag(atsc_ctx *ctx, int on)
@@ -429,13 +458,30 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         ctx->diag_stream = s;
         d_diag = ctx->d_diag;
     }
+    int dominant = 0;
+    for (int c = 1; c < N_CLASSES; ++c)
+        if (plan->class_count[c] > plan->class_count[dominant]) dominant = c;
     for (int c = 0; c < N_CLASSES; ++c) {
         if (!plan->class_count[c]) continue;
+        const bool timed = ctx->profiling && c == dominant;
+        if (timed) {
+            if (ctx->ev_used == ctx->ev_pool.size()) {
+                hipEvent_t a, b;
+                HIPCHK(ctx, hipEventCreate(&a));
+                HIPCHK(ctx, hipEventCreate(&b));
+                ctx->ev_pool.emplace_back(a, b);
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].first, s));
+        }
         hipError_t e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
                                              plan->d_frames, plan->d_ids + plan->class_first[c],
                                              plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
                                              plan->d_res, d_diag, s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
+        if (timed) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].second, s));
+            ctx->ev_used++;
+        }
     }
     hipError_t e = launch_pack(plan->d_frames, plan->d_res, plan->n_frames, plan->d_local,
                                plan->d_blocksum, plan->d_slots, d_body, body_cap, d_rec_off,

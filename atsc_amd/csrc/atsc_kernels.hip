@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 for (int m = 0; m < SPL; ++m) {
                     if (tid + m * T < L) {
                         const double v = (double)(acc[m] + dc);
-                        double o = round(v * 100000.0) * 1.0e-5;  // fft.rs:208-218
+                        double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
                         if (o > mxd) o = mxd;
                         if (o < mnd) o = mnd;
                         s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                             const double sv = spline_eval(
                                 [&](uint32_t k) { return xs[(k == K - 1) ? (n - 1) : k * step]; },
                                 j - pre, n, step, K, magic);
-                            double o = round(sv * 100000.0) * 1.0e-5;  // utils/mod.rs:66-74
+                            double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
                             if (o < smin) o = smin;
                             else if (o > smax) o = smax;
                             s += fabs(o - g[m]) * inv[m];

@@ -40,6 +40,16 @@ class Context:
         capi.check(capi.lib().atsc_ctx_last_diag(self._h, arr, n_frames), self._h)
         return arr
 
+    def set_profiling(self, on=True):
+        capi.check(capi.lib().atsc_ctx_set_profiling(self._h, int(on)), self._h)
+
+    def profile_read(self):
+        """-> (summed ms of the dominant k_compress launches, number of launches)"""
+        ms = C.c_double()
+        cnt = C.c_uint64()
+        capi.check(capi.lib().atsc_ctx_profile_read(self._h, C.byref(ms), C.byref(cnt)), self._h)
+        return ms.value, cnt.value
+
     # ---- host-pointer convenience ----------------------------------------------------------
     def compress_host(self, samples, frame_off, compressor=capi.AUTO, bounded=True, max_error=0.03,
                       level=0):

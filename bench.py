@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native ATSC compressor path.
+
+Metric (BASELINE.json): Msamples/sec compressed (auto, e=5%) + ratio.
+Workload at every N: BASELINE.json configs[2] per GPU -- 10,485,760 synthetic f64 samples in
+40960 frames of 256 (classes C0..C4 cycled per 65536-sample block, series id =
+rank), `--compressor auto`, max_error = (float)5/100.  One "step" = one pass of the hot path
+(per-frame FFT / Catmull-Rom / RLE / Constant fit + error check + selector + BRO record packing)
+over that batch with the samples already resident in HBM.  N > 1: one process per GPU
+(torch.distributed, backend nccl = RCCL); frames shard by rank with no data-path collective;
+the only exchange is the gather of the encoded records to rank 0 (sizes all-gather + P2P),
+which is inside the timed region.  Scaling is weak (per-GPU work fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SAMPLES = 10485760
+FRAME = 256
+ERROR_PCT = 5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(x, off, me, frames_per_block=256, blocks=160):
+    """Times the CPU oracle (C restatement of the reference algorithm, single thread) on a bounded
+    sample of the same workload: the first `frames_per_block` frames of each of the first `blocks`
+    65536-sample blocks (so every class appears in the workload's proportion).  The defaults take
+    the whole batch (40960 frames, about 5 s of CPU work)."""
+    from oracle import oracle as orc
+
+    orc.build()
+    idx = []
+    per_block = 65536 // FRAME
+    for b in range(blocks):
+        idx.extend(range(b * per_block, b * per_block + frames_per_block))
+    xs = np.concatenate([x[int(off[i]):int(off[i + 1])] for i in idx])
+    so = np.arange(0, len(xs) + 1, FRAME, dtype=np.uint64)
+    orc.stream_compress(xs[: FRAME * 8], so[:9], orc.AUTO, True, me, 0)  # warm-up
+    t0 = time.perf_counter()
+    bro, _, _ = orc.stream_compress(xs, so, orc.AUTO, True, me, 0)
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(xs) / dt / 1e6,
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d frames x %d (first %d frames of each of the first %d class blocks), %.1f s, "
+                  "C restatement of the reference algorithm (oracle/), 1 thread, ratio %.2f" % (
+                      len(idx), FRAME, frames_per_block, blocks, dt, 8.0 * len(xs) / len(bro)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the compressor")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as G
+
+    G.build()
+    import atsc_amd
+    from tests import helpers as H
+
+    me = float(np.float32(ERROR_PCT) / np.float32(100))
+    x = H.synth_series(rank, N_SAMPLES)
+    off = H.frame_offsets(N_SAMPLES, FRAME)
+    ctx = atsc_amd.Context(local_rank)
+    plan = ctx.plan(off)
+    d_x = torch.from_numpy(x).to(dev)
+    outs = plan.alloc_outputs(torch, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gather_buf = None
+    sizes_dev = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
+
+    def step():
+        plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, stream)
+        if world > 1:
+            # the path's only exchange: concatenate the encoded records on rank 0
+            dist.all_gather_into_tensor(sizes_dev, outs["rec_off"][-1:].contiguous())
+            sizes = sizes_dev.tolist()
+            if rank == 0:
+                nonlocal gather_buf
+                need = sum(sizes)
+                if gather_buf is None or gather_buf.numel() < need:
+                    gather_buf = torch.empty(int(need * 1.25) + 16, dtype=torch.uint8, device=dev)
+                pos = sizes[0]
+                gather_buf[:pos].copy_(outs["body"][:pos])
+                reqs = []
+                for r in range(1, world):
+                    reqs.append(dist.irecv(gather_buf[pos:pos + sizes[r]], src=r))
+                    pos += sizes[r]
+                for q in reqs:
+                    q.wait()
+            else:
+                dist.send(outs["body"][:sizes[rank]], dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = ctx.profile_read()
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    body_bytes = int(outs["rec_off"][-1].item())
+    if world > 1:
+        t = torch.tensor([body_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_body = int(t.item())
+    else:
+        total_body = body_bytes
+
+    if rank == 0:
+        total_samples = N_SAMPLES * world
+        value = total_samples * args.steps / dt / 1e6
+        chosen = outs["chosen"].cpu().numpy()
+        codecs = {atsc_amd.capi.COMPRESSOR_NAMES[int(c)]: int(np.sum(chosen == c)) for c in np.unique(chosen)}
+        # roofline of the dominant kernel (k_compress<1,5>: every 256-sample frame of the batch).
+        # Algorithmic bytes per launch: 8 B read per input sample + encoded record bytes.
+        algo_bytes = 8.0 * N_SAMPLES + body_bytes
+        k_avg_ms = kern_ms / max(launches, 1)
+        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_compress_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec compressed (auto, e=5%)",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "ratio": 8.0 * total_samples / (total_body + 9 * world + 3 * world),
+            "config": {
+                "workload": "BASELINE.json configs[2] per GPU: 10,485,760 f64 samples, 40960 frames x 256, "
+                            "--compressor auto, e=5% (max_error=(float)5/100), classes C0-C4 cycled per "
+                            "65536-sample block, inputs resident in HBM",
+                "frames_per_gpu": plan.n_frames,
+                "frame_len": FRAME,
+                "codecs_rank0": codecs,
+                "encoded_bytes_rank0": body_bytes,
+                "parallelism": "frames sharded by rank (%d), RCCL gather of records to rank 0" % world
+                               if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_compress<1,5>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms_avg": k_avg_ms,
+                "kernel_launches": launches,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x, off, me)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,13 @@ typedef struct {
 int atsc_ctx_enable_diag(atsc_ctx *ctx, int on);
 int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t n_frames);
 
+/* Kernel timing for the roofline report: when on, every atsc_compress_plan_dev records a HIP
+ * event pair (on the launch stream) around the k_compress launch of the frame class holding
+ * the most frames.  atsc_ctx_profile_read waits for them, returns the summed milliseconds and
+ * the number of launches, and resets the counters. */
+int atsc_ctx_set_profiling(atsc_ctx *ctx, int on);
+int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *launches);
+
 /* Host-pointer convenience: plan + H2D + compress + D2H, synchronous.
  * body_len receives the number of bytes written to `body`. */
 int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,

@@ -122,7 +122,7 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
             if verdict != "boundary":
                 # reported error: exact codecs report 0.0; lossy within tolerance
                 tol = FFT_ERR_ATOL if tag == oracle.FFT else max(POLY_ERR_RTOL * abs(eo), 1e-300)
-                if not (abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
+                if not (err[i] == eo or abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
                     summary["fail"].append((i, "FAIL:err gpu=%r oracle=%r" % (err[i], eo)))
     return summary
 
