@@ -101,30 +101,19 @@ def main():
     outs = plan.alloc_outputs(torch, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather_buf = None
+    from atsc_amd import parallel
+
+    gstate = {"buf": None}
     sizes_dev = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
 
     def step():
         plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, stream)
         if world > 1:
             # the path's only exchange: concatenate the encoded records on rank 0
-            dist.all_gather_into_tensor(sizes_dev, outs["rec_off"][-1:].contiguous())
-            sizes = sizes_dev.tolist()
+            got, _ = parallel.gather_records(dist, torch, outs["body"], outs["rec_off"][-1:], rank,
+                                             world, sizes_dev, gstate["buf"])
             if rank == 0:
-                nonlocal gather_buf
-                need = sum(sizes)
-                if gather_buf is None or gather_buf.numel() < need:
-                    gather_buf = torch.empty(int(need * 1.25) + 16, dtype=torch.uint8, device=dev)
-                pos = sizes[0]
-                gather_buf[:pos].copy_(outs["body"][:pos])
-                reqs = []
-                for r in range(1, world):
-                    reqs.append(dist.irecv(gather_buf[pos:pos + sizes[r]], src=r))
-                    pos += sizes[r]
-                for q in reqs:
-                    q.wait()
-            else:
-                dist.send(outs["body"][:sizes[rank]], dst=0)
+                gstate["buf"] = got
 
     for _ in range(args.warmup):
         step()
