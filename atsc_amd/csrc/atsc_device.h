@@ -127,13 +127,67 @@ DEVI uint32_t put_value(uint8_t *p, uint32_t bitdepth, double v)
 }
 
 // --------------------------------------------------------------------------------------------
+// wavefront reductions on the DPP crossbar (no LDS): quad_perm, row_ror, row_bcast; the total
+// lands in lane 63 and is broadcast through an SGPR (v_readlane).
+// --------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK>
+DEVI uint32_t dpp_u32(uint32_t v)  // lanes without a source read 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK>
+DEVI uint32_t dpp_u32_keep(uint32_t v, uint32_t ident)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+DEVI uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp_u32<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_u32<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_u32<0x124, 0xf>(v);  // row_ror:4
+    v += dpp_u32<0x128, 0xf>(v);  // row_ror:8
+    v += dpp_u32<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+DEVI uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<0xb1, 0xf>(v));
+    v = max(v, dpp_u32<0x4e, 0xf>(v));
+    v = max(v, dpp_u32<0x124, 0xf>(v));
+    v = max(v, dpp_u32<0x128, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+DEVI uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+template <int CTRL, int ROWMASK>
+DEVI double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+DEVI double wave_sum_f64(double v)
+{
+    v += dpp_f64<0xb1, 0xf>(v);
+    v += dpp_f64<0x4e, 0xf>(v);
+    v += dpp_f64<0x124, 0xf>(v);
+    v += dpp_f64<0x128, 0xf>(v);
+    v += dpp_f64<0x142, 0xa>(v);
+    v += dpp_f64<0x143, 0xc>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// --------------------------------------------------------------------------------------------
 // workgroup collectives (W wavefronts).  All return the same bits in every thread.
 // --------------------------------------------------------------------------------------------
 template <int W>
 DEVI double block_sum_f64(double v, double *red, int &parity)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum_f64(v);
     if (W == 1) return v;
     double *r = red + parity * 16;
     parity ^= 1;
@@ -147,8 +201,7 @@ DEVI double block_sum_f64(double v, double *red, int &parity)
 template <int W>
 DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum_u32(v);
     if (W == 1) return v;
     uint32_t *r = (uint32_t *)(red + parity * 16);
     parity ^= 1;
@@ -158,6 +211,23 @@ DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
 #pragma unroll
     for (int w = 1; w < W; ++w) s += r[w];
     return s;
+}
+
+// x mod L with a precomputed magic = floor(2^32 / L) + 1 (L >= 2, any 32-bit x): the estimated
+// quotient is exact or one too large.
+DEVI uint32_t mod_magic(uint32_t x, uint32_t L, uint32_t magic)
+{
+    uint32_t r = x - __umulhi(x, magic) * L;
+    if (r >= L) r += L;
+    return r;
+}
+// a / d for small non-negative integers a <= d <= 4096 (spline parameter r / gap), correctly
+// rounded: q = a*y with y = RN(1/d), one FMA residual step.  Checked exhaustively for all pairs.
+DEVI double div_small(double a, double d, double y)
+{
+    const double q = a * y;
+    const double rem = fma(-q, d, a);
+    return fma(rem, y, q);
 }
 
 // In-place exclusive scan of an LDS u32 array; returns the total.  Each thread owns a

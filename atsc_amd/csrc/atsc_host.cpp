@@ -172,6 +172,7 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
     }
     p.p2bins = pow2_ge(p.bins);
     p.p2n = pow2_ge(n);
+    p.magicL = p.L >= 2 ? (uint32_t)(0x100000000ull / p.L) + 1u : 0u;
     uint32_t o = 0;
     p.o_red = o; o += 512;
     p.o_xs = o; o += align16(8 * n);

@@ -20,6 +20,7 @@ struct DevPlan {
     uint32_t radix[14];
     uint32_t p2bins;   // power of two >= bins (sort network size)
     uint32_t p2n;      // power of two >= n
+    uint32_t magicL;   // floor(2^32 / L) + 1 (L >= 2): x mod L without a divide
     uint32_t lds_bytes;
     // LDS carve offsets (bytes, 16-aligned)
     uint32_t o_xs, o_tw, o_a, o_b, o_sel, o_aux, o_red;

@@ -148,7 +148,13 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     // ---- load samples + twiddles ----------------------------------------------------------
     {
         const double *src = samples + fr.sample_off;
-        for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
+        if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
+            const double2 *src2 = (const double2 *)src;
+            double2 *xs2 = (double2 *)xs;
+            for (uint32_t j = tid; j < (n >> 1); j += T) xs2[j] = src2[j];
+        } else {
+            for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
+        }
         const float2 *twp = twpool + P.tw_off;
         for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
     }
@@ -286,18 +292,37 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 __syncthreads();
                 spec = fft_forward<W>(P, A, B, tw);
             }
+            // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
+            // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
+            // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
+            // W > 1: one sort of 64-bit keys up front.
+            constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
+            uint32_t nb[KPL];
             uint64_t *keys = (uint64_t *)(spec == A ? B : A);
-            // fft.rs:88-106 order by f32 norm = hypot(re, im); ties broken by position (ascending)
             uint32_t nz = 0;
-            for (uint32_t k = tid; k < bins; k += T) {
-                const float2 z = spec[k];
-                const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-                keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
-                nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+            if (W == 1) {
+#pragma unroll
+                for (int m = 0; m < KPL; ++m) {
+                    const uint32_t k = tid + 64 * m;
+                    nb[m] = 0;
+                    if (k < bins) {
+                        const float2 z = spec[k];
+                        nb[m] = __float_as_uint(
+                            (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+                        nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                    }
+                }
+            } else {
+                for (uint32_t k = tid; k < bins; k += T) {
+                    const float2 z = spec[k];
+                    const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                    keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
+                    nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
-            block_sort<W, true>(keys, nullptr, bins, P.p2bins);
+            if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
 
             float acc[SPL];
 #pragma unroll
@@ -305,14 +330,33 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             float dc = 0.0f;
             const double mxd = (double)mxf, mnd = (double)mnf;
             const double Ld = (double)L;
-            uint32_t used = 0, jump = 0;
+            const uint32_t magicL = P.magicL;
+            uint32_t used = 0, jump = 0, big = 0;
             double cur = prm.max_err + 1.0;
             while (prm.max_err_m < sat_i32(cur * 1000.0)) {  // fft.rs:334
                 ++fft_trips;
                 const uint32_t K = min(P.mf + jump, Z);
                 for (; used < K; ++used) {
-                    const uint32_t pos = (uint32_t)(keys[used] & 0xffffffffu);
+                    uint32_t pos;
+                    if (W == 1) {
+                        uint32_t lm = nb[0];
+#pragma unroll
+                        for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
+                        const uint32_t wm = wave_max_u32(lm);
+                        uint32_t cand = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int m = KPL - 1; m >= 0; --m)
+                            if (nb[m] == wm) cand = tid + 64 * m;
+                        pos = wave_min_u32(cand);
+#pragma unroll
+                        for (int m = 0; m < KPL; ++m)
+                            if (tid + 64 * m == pos) nb[m] = 0;
+                    } else {
+                        pos = (uint32_t)(keys[used] & 0xffffffffu);
+                    }
                     const float2 z = spec[pos];
+                    if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
+                    big += (pos >= 251) ? 1u : 0u;
                     // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once
                     const double cf = (pos == 0 || 2 * pos == L) ? 1.0 : 2.0;
                     const float a = (float)(cf * (double)z.x / Ld);
@@ -320,8 +364,8 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                     if (pos == 0) {
                         dc = a;
                     } else {
-                        uint32_t idx = (pos * tid) % L;
-                        const uint32_t stp = (pos * (uint32_t)T) % L;
+                        uint32_t idx = mod_magic(pos * tid, L, magicL);
+                        const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
 #pragma unroll
                         for (int m = 0; m < SPL; ++m) {
                             if (tid + m * T < L) {
@@ -353,16 +397,8 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             }
             fft_err = cur;
             fft_k = used;
-            uint32_t big = 0;
-            for (uint32_t i = tid; i < used; i += T) {
-                const uint32_t pos = (uint32_t)(keys[i] & 0xffffffffu);
-                const float2 z = spec[pos];
-                sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
-                big += (pos >= 251) ? 1u : 0u;
-            }
-            __syncthreads();
-            big = block_sum_u32<W>(big, red, parity);
             fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+            __syncthreads();  // sel[] is complete; A/B may be reused from here on
         }
         dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
         dg.fft_err = fft_err;
@@ -381,6 +417,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         } else {
             const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
             const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+            double2 *mm = (double2 *)A;  // per-segment Hermite tangents (m0, m1); A|B is free here
             double cur = prm.max_err + 1.0;
             uint32_t jump = 0;
             while (prm.poly_target < round(cur * 10000.0) / 10000.0) {
@@ -392,15 +429,59 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 poly_step = step;
                 poly_K = K;
                 if (step > 1) {
+                    // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
+                    // the first and the last two (polynomial.rs:349-353).  The tangents of a segment
+                    // are the same for all its samples: compute them once per segment, in the
+                    // crate's operation order (oracle: cubic_hermite).
                     const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+                    const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
+                    const double stepd = (double)step, gapLd = (double)gapL;
+                    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                    __syncthreads();
+                    for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
+                        const uint32_t t0i = sg * step;
+                        const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                        const uint32_t tmi = (sg - 1) * step;
+                        const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                        const double t0 = (double)t0i, t1 = (double)t1i;
+                        const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+                        double2 t;
+                        t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                        t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                        mm[sg] = t;
+                    }
+                    __syncthreads();
                     double s = 0.0;
 #pragma unroll
                     for (int m = 0; m < SPL; ++m) {
                         const uint32_t j = tid + m * T;
                         if (j >= pre && j < pre + n) {
-                            const double sv = spline_eval(
-                                [&](uint32_t k) { return xs[(k == K - 1) ? (n - 1) : k * step]; },
-                                j - pre, n, step, K, magic);
+                            const uint32_t i = j - pre;
+                            double sv;
+                            if (i == n - 1) {
+                                sv = xs[n - 1];
+                            } else {
+                                uint32_t sg = __umulhi(i, magic);  // i / step
+                                if (sg > K - 2) sg = K - 2;
+                                const uint32_t t0i = sg * step;
+                                const bool last = (sg == K - 2);
+                                const uint32_t t1i = last ? (n - 1) : t0i + step;
+                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                            last ? ryL : ry);
+                                const double v0 = xs[t0i], v1 = xs[t1i];
+                                if (sg > 0 && K - sg > 2) {
+                                    const double2 t = mm[sg];
+                                    const double t2 = nt * nt;
+                                    const double t3 = t2 * nt;
+                                    const double two_t3 = t3 * 2.0;
+                                    const double two_t2 = t2 * 2.0;
+                                    const double three_t2 = t2 * 3.0;
+                                    sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
+                                         v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
+                                } else {
+                                    sv = v0 * (1.0 - nt) + v1 * nt;
+                                }
+                            }
                             double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
                             if (o < smin) o = smin;
                             else if (o > smax) o = smax;
@@ -420,11 +501,15 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         // size: polynomial.rs:54-87
         uint32_t vb = 0;
-        for (uint32_t k = tid; k < poly_K; k += T) {
-            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
-            vb += value_bytes(bitdepth, xs[t]);
+        if (bitdepth == 0 || bitdepth == 3) {
+            vb = poly_K * (bitdepth == 0 ? 8u : 1u);
+        } else {
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                vb += value_bytes(bitdepth, xs[t]);
+            }
+            vb = block_sum_u32<W>(vb, red, parity);
         }
-        vb = block_sum_u32<W>(vb, red, parity);
         poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
         dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
         dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
@@ -441,62 +526,104 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     uint32_t *rends = rstart + n;               // 4n  (later: group head positions hp[])
     uint32_t *rps = (uint32_t *)tw;             // 4n  prefix of index varint bytes
     uint32_t *rph = rps + n;                    // 4n  prefix of group header bytes
+    uint32_t rle_ib = 0;
+    // Sorts the runs by (value bits, start) = BTreeMap order (rle.rs:146,158-169,180-182) and sizes
+    // the groups.  Leaves: rkeys/rstart sorted, aux[i] = heads before i, rends[g] = head index of
+    // group g (rends[D] = R), rph[g] = header bytes of group g.
+    auto rle_sort_and_group = [&]() {
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += T)
+            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;  // run ends (rle.rs:154)
+        __syncthreads();
+        const uint32_t R = block_excl_scan<W>(aux, n, wsum);
+        for (uint32_t j = tid; j < n; j += T)
+            if (j + 1 >= n || xs[j + 1] != xs[j]) rends[aux[j]] = j;
+        __syncthreads();
+        for (uint32_t r = tid; r < R; r += T) {
+            rkeys[r] = (uint64_t)__double_as_longlong(xs[rends[r]]);
+            rstart[r] = r ? rends[r - 1] + 1 : 0;
+        }
+        __syncthreads();
+        uint32_t p2 = 1;
+        while (p2 < R) p2 <<= 1;
+        block_sort<W, false>(rkeys, rstart, R, p2);
+        for (uint32_t i = tid; i < R; i += T)
+            aux[i] = (i == 0 || rkeys[i] != rkeys[i - 1]) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t D = block_excl_scan<W>(aux, R, wsum);
+        for (uint32_t i = tid; i < R; i += T)
+            if (i == 0 || rkeys[i] != rkeys[i - 1]) rends[aux[i]] = i;  // hp[g]
+        if (tid == 0) rends[D] = R;
+        __syncthreads();
+        uint32_t hb = 0;
+        for (uint32_t gi = tid; gi < D; gi += T) {
+            const uint32_t h0 = rends[gi], h1 = rends[gi + 1];
+            const uint32_t b = value_bytes(bitdepth, __longlong_as_double((long long)rkeys[h0])) +
+                               vlen(h1 - h0);
+            rph[gi] = b;
+            hb += b;
+        }
+        __syncthreads();
+        hb = block_sum_u32<W>(hb, red, parity);
+        rle_R = R;
+        rle_D = D;
+        rle_size = 2 + vlen(D) + hb + rle_ib;
+        rle_sorted = true;
+    };
     if (run_rle) {
         const double me = prm.max_err;
         const bool pf = run_fft && (fft_err <= me), pp = run_poly && (poly_err <= me);
         uint32_t best_other = 0xFFFFFFFFu;
         if (pf) best_other = fft_size;
         if (pp && poly_size < best_other) best_other = poly_size;
-        // run ends: x[j+1] != x[j] (rle.rs:154)
+        // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
+        uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
         for (uint32_t j = tid; j < n; j += T)
-            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
-        __syncthreads();
-        const uint32_t R = block_excl_scan<W>(aux, n, wsum);
+            if (j == 0 || xs[j] != xs[j - 1]) pk += (vlen(j) << 13) | 1u;
+        pk = block_sum_u32<W>(pk, red, parity);
+        const uint32_t R = pk & 0x1fffu, ib = pk >> 13;
         rle_R = R;
-        for (uint32_t j = tid; j < n; j += T)
-            if (j + 1 >= n || xs[j + 1] != xs[j]) rends[aux[j]] = j;
-        __syncthreads();
-        uint32_t ib = 0;
-        for (uint32_t r = tid; r < R; r += T) {
-            const uint32_t e = rends[r];
-            const uint32_t st = r ? rends[r - 1] + 1 : 0;
-            rkeys[r] = (uint64_t)__double_as_longlong(xs[e]);
-            rstart[r] = st;
-            ib += vlen(st);
-        }
-        __syncthreads();
-        ib = block_sum_u32<W>(ib, red, parity);
+        rle_ib = ib;
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
         const uint32_t lb = 3 + ib + (R >= 2 ? 2u : 1u) * (minval + 1);
         if (mode == ATSC_RLE || lb < best_other) {
-            uint32_t p2 = 1;
-            while (p2 < R) p2 <<= 1;
-            block_sort<W, false>(rkeys, rstart, R, p2);
-            rle_sorted = true;
-            for (uint32_t i = tid; i < R; i += T)
-                aux[i] = (i == 0 || rkeys[i] != rkeys[i - 1]) ? 1u : 0u;
-            __syncthreads();
-            const uint32_t D = block_excl_scan<W>(aux, R, wsum);
-            rle_D = D;
-            for (uint32_t i = tid; i < R; i += T)
-                if (i == 0 || rkeys[i] != rkeys[i - 1]) rends[aux[i]] = i;  // hp[g]
-            if (tid == 0) rends[D] = R;
-            __syncthreads();
-            uint32_t hb = 0;
-            for (uint32_t gi = tid; gi < D; gi += T) {
-                const uint32_t h0 = rends[gi], h1 = rends[gi + 1];
-                const uint32_t b = value_bytes(bitdepth, __longlong_as_double((long long)rkeys[h0])) +
-                                   vlen(h1 - h0);
-                rph[gi] = b;
-                hb += b;
+            if (R <= 64 || mode == ATSC_RLE) {
+                rle_sort_and_group();
+            } else {
+                // Exact size without sorting: count distinct run values and their multiplicities in
+                // an LDS hash table (A|B is free: 4L slots of u32 run-end indices).
+                uint32_t *tab = (uint32_t *)A;
+                const uint32_t H = 4 * L;
+                __syncthreads();
+                for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
+                for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
+                __syncthreads();
+                uint32_t dnew = 0;
+                for (uint32_t j = tid; j < n; j += T) {
+                    if (j + 1 >= n || xs[j + 1] != xs[j]) {
+                        const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
+                        uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
+                            if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
+                            if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
+                            h = (h + 1 == H) ? 0 : h + 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t hb = 0;
+                for (uint32_t j = tid; j < n; j += T)
+                    if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
+                // (distinct << 18 | header bytes): header bytes <= 11 * 4096 < 2^18
+                const uint32_t pk2 = block_sum_u32<W>((dnew << 18) | hb, red, parity);
+                rle_D = pk2 >> 18;
+                rle_size = 2 + vlen(rle_D) + (pk2 & 0x3ffffu) + ib;
             }
-            __syncthreads();
-            hb = block_sum_u32<W>(hb, red, parity);
-            rle_size = 2 + vlen(D) + hb + ib;
         } else {
             rle_size = lb;  // a lower bound that already cannot win
         }
-        dg.rle_size = rle_sorted ? rle_size : 0xFFFFFFFEu;
+        dg.rle_size = (mode == ATSC_RLE || lb < best_other) ? rle_size : 0xFFFFFFFEu;
     }
 
     // =========================================================================================
@@ -562,6 +689,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         out_len = hdr + body + 17;
     } else {  // RLE: rle.rs:40-67
         // records are sorted by (value bits, start); aux[i] = heads before i; rends = hp[]; rph = hb[]
+        if (!rle_sorted) rle_sort_and_group();
         const uint32_t R = rle_R, D = rle_D;
         const uint32_t hdr = 2 + vlen(D);
         for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rstart[i]);
