@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
 
     double *xs = (double *)(smem + P.o_xs);      // 8n : knot values / rle group values
     float2 *tw = (float2 *)(smem + P.o_tw);      // 8L
-    unsigned char *AB = smem + P.o_a;            // >= 16L + 8 bytes, contiguous A|B
+    unsigned char *AB = smem + P.o_ab;           // >= 16L + 8 bytes, contiguous A|B
     uint32_t *aux = (uint32_t *)(smem + P.o_aux);  // 4(n+2)
     double *red = (double *)(smem + P.o_red);
     // header scalars broadcast through LDS (written by lane 0)

@@ -213,6 +213,78 @@ DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
     return s;
 }
 
+// wavefront min / max of f64 by compare-select (no v_min_f64: NaN and signed-zero behaviour must be
+// the plain `<` / `>` of the reference's scan).  Lanes without a DPP source read themselves.
+template <int CTRL, int ROWMASK>
+DEVI double dpp_f64_self(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool IsMin>
+DEVI double wave_minmax_f64(double v)
+{
+#define ATSC_MM_STEP(CTRL, RM)                                   \
+    {                                                            \
+        const double o = dpp_f64_self<CTRL, RM>(v);              \
+        v = (IsMin ? (o < v) : (o > v)) ? o : v;                 \
+    }
+    ATSC_MM_STEP(0xb1, 0xf)
+    ATSC_MM_STEP(0x4e, 0xf)
+    ATSC_MM_STEP(0x124, 0xf)
+    ATSC_MM_STEP(0x128, 0xf)
+    ATSC_MM_STEP(0x142, 0xa)
+    ATSC_MM_STEP(0x143, 0xc)
+#undef ATSC_MM_STEP
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+template <int W, bool IsMin>
+DEVI double block_minmax_f64(double v, double *red, int &parity)
+{
+    v = wave_minmax_f64<IsMin>(v);
+    if (W == 1) return v;
+    double *r = red + parity * 16;
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = r[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+        const double o = r[w];
+        s = (IsMin ? (o < s) : (o > s)) ? o : s;
+    }
+    return s;
+}
+template <int W>
+DEVI uint32_t block_min_u32(uint32_t v, double *red, int &parity)
+{
+    v = wave_min_u32(v);
+    if (W == 1) return v;
+    uint32_t *r = (uint32_t *)(red + parity * 16);
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t s = r[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s = min(s, r[w]);
+    return s;
+}
+template <int W>
+DEVI uint32_t block_or_u32(uint32_t v, double *red, int &parity)
+{
+    return block_sum_u32<W>(v ? 1u : 0u, red, parity) ? 1u : 0u;
+}
+// "fractional part is non-zero" exactly as optimizer/utils.rs:115-160 split_n(x).1 != 0.0 decides
+// it, without the bit surgery: checked against the literal port on 16.4 M bit patterns covering
+// every exponent (subnormals, |x| >= 2^52, NaN, Inf, both signs).
+DEVI bool frac_nonzero(double x)
+{
+    return (x != trunc(x)) && (x == x) && (x >= 0x1p-64 || x <= -0x1p-75);
+}
+
 // x mod L with a precomputed magic = floor(2^32 / L) + 1 (L >= 2, any 32-bit x): the estimated
 // quotient is exact or one too large.
 DEVI uint32_t mod_magic(uint32_t x, uint32_t L, uint32_t magic)

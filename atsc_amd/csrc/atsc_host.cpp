@@ -45,6 +45,7 @@ struct atsc_ctx {
     uint64_t diag_n = 0;
     hipStream_t diag_stream = nullptr;
     bool want_diag = false;
+    int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
     // optional timing of the dominant k_compress launch (HIP events on the launch stream)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -162,23 +163,35 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
     p.dk1 = std::max(p.mf / 2, 1u);
     p.dk2 = std::max(p.mf / 10, 1u);
     p.kcap = std::min(p.bins, p.mf + 17 * p.dk1 + 5 * p.dk2);
+    p.half = (!p.direct && p.L % 2 == 0) ? 1 : 0;
+    p.M = p.half ? p.L / 2 : p.L;
+    p.sc = p.L / p.M;
     if (!p.direct) {
-        uint32_t l = p.L, s = 0;
-        while (l % 4 == 0) { p.radix[s++] = 4; l /= 4; }
-        while (l % 2 == 0) { p.radix[s++] = 2; l /= 2; }
-        while (l % 3 == 0) { p.radix[s++] = 3; l /= 3; }
-        if (l != 1 || s > 14) return ATSC_E_INVALID;
+        uint32_t l = p.M, s = 0, st = 1;
+        auto push = [&](uint32_t r) {
+            p.radix[s] = r;
+            p.stmagic[s] = st >= 2 ? (uint32_t)(0x100000000ull / st) + 1u : 0u;  // st == 1: p = t
+            st *= r;
+            ++s;
+        };
+        while (l % 4 == 0 && s < 14) { push(4); l /= 4; }
+        while (l % 2 == 0 && s < 14) { push(2); l /= 2; }
+        while (l % 3 == 0 && s < 14) { push(3); l /= 3; }
+        if (l != 1) return ATSC_E_INVALID;
         p.nstages = s;
     }
     p.p2bins = pow2_ge(p.bins);
     p.p2n = pow2_ge(n);
     p.magicL = p.L >= 2 ? (uint32_t)(0x100000000ull / p.L) + 1u : 0u;
+    // AB: FFT ping-pong (8 B per complex point, +8 so the second buffer can hold bins = M+1 values),
+    // and at least 8n+64 bytes for the RLE run records / hash table and the spline tables.
+    p.ab_half = align16(p.direct ? 8 * p.bins : 8 * p.M + 8);
+    p.ab_bytes = std::max(2 * p.ab_half, align16(8 * n + 64));
     uint32_t o = 0;
-    p.o_red = o; o += 512;
+    p.o_red = o; o += 384;
     p.o_xs = o; o += align16(8 * n);
     p.o_tw = o; o += align16(8 * std::max(p.L, n));  // also hosts two u32[n] arrays for RLE
-    p.o_a = o; o += align16(8 * std::max(p.L, n));
-    p.o_b = o; o += align16(8 * std::max(p.L, n) + 8);
+    p.o_ab = o; o += p.ab_bytes;
     p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
     p.o_aux = o; o += align16(4 * (n + 2));
     p.lds_bytes = o;
@@ -255,6 +268,7 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
     if (!c) return ATSC_E_NOMEM;
     c->device = device;
     c->want_diag = getenv("ATSC_DIAG") != nullptr;
+    if (const char *ds = getenv("ATSC_DEBUG_STOP")) c->debug_stop = atoi(ds);
     *out = c;
     return ATSC_OK;
 }
@@ -447,6 +461,7 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     prm.mode = compressor;
     prm.bounded = bounded;
     prm.want_diag = ctx->want_diag;
+    prm.debug_stop = ctx->debug_stop;
     atsc_frame_diag *d_diag = nullptr;
     if (ctx->want_diag) {
         if (ctx->diag_cap < plan->n_frames) {

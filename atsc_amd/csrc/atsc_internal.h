@@ -16,14 +16,19 @@ struct DevPlan {
     uint32_t dk2;      // max(mf/10, 1) (fft.rs:350)
     uint32_t kcap;     // min(bins, mf + 17*dk1 + 5*dk2): most bins the ladder can ever store
     uint32_t direct;   // 1: O(n^2) DFT (n < 128, any n incl. primes); 0: Stockham 2^a 3^b
+    uint32_t half;     // 1: L even -> one complex FFT of length M = L/2 over the packed real signal
+    uint32_t M;        // FFT length actually run through the Stockham stages (L or L/2)
+    uint32_t sc;       // L / M: index scale into the length-L twiddle table
     uint32_t nstages;
     uint32_t radix[14];
+    uint32_t stmagic[14];  // floor(2^32 / stride_s) + 1 for t / stride_s (stride_s = product of earlier radices)
     uint32_t p2bins;   // power of two >= bins (sort network size)
     uint32_t p2n;      // power of two >= n
     uint32_t magicL;   // floor(2^32 / L) + 1 (L >= 2): x mod L without a divide
     uint32_t lds_bytes;
-    // LDS carve offsets (bytes, 16-aligned)
-    uint32_t o_xs, o_tw, o_a, o_b, o_sel, o_aux, o_red;
+    // LDS carve offsets (bytes, 16-aligned).  AB = two FFT work buffers of ab_half bytes each,
+    // later reused for spline tables, RLE run records and the RLE hash table.
+    uint32_t o_xs, o_tw, o_ab, ab_half, ab_bytes, o_sel, o_aux, o_red;
     uint64_t tw_off;   // offset (in float2 entries) of this L's table in the twiddle pool
 };
 
@@ -47,6 +52,7 @@ struct KParams {
     int32_t mode;        // ATSC_* compressor id
     int32_t bounded;
     int32_t want_diag;
+    int32_t debug_stop;  // profiling aid: leave the kernel after phase N (0 = run everything)
 };
 
 // parsed frame record for decompression

@@ -30,8 +30,8 @@ namespace atsc {
 
 // --------------------------------------------------------------------------------------------
 // forward transform, complex f32, unnormalised, e^{-i...}  (rustfft plan_fft_forward)
-// Stockham autosort, radices 4/2/3; tw[t] = (cos, sin)(2 pi t / L).
-// Returns the buffer that holds the result.
+// Stockham autosort of length M = P.M, radices 4/2/3; tw[t] = (cos, sin)(2 pi t / L) is the
+// length-L table, so the stage twiddle w_M^e is tw[e * P.sc].  Returns the result buffer.
 // --------------------------------------------------------------------------------------------
 DEVI float2 cmul_conj_tw(float2 v, float2 w)  // v * (w.x - i w.y)
 {
@@ -41,18 +41,20 @@ template <int W>
 DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw)
 {
     constexpr int T = 64 * W;
-    const uint32_t L = P.L;
-    uint32_t ncur = L, st = 1;
+    const uint32_t M = P.M, sc = P.sc;
+    uint32_t ncur = M, st = 1;
     for (uint32_t s = 0; s < P.nstages; ++s) {
         const uint32_t r = P.radix[s];
         const uint32_t m = ncur / r;
-        const uint32_t nb = L / r;
+        const uint32_t nb = M / r;
+        const uint32_t magic = P.stmagic[s];
+        const uint32_t sm = st * m;
         for (uint32_t t = threadIdx.x; t < nb; t += T) {
-            const uint32_t p = t / st, q = t - p * st;
+            const uint32_t p = (st == 1) ? t : __umulhi(t, magic);  // t / st
+            const uint32_t q = t - p * st;
             const uint32_t ib = q + st * p;        // + st*m*j
             const uint32_t ob = q + st * (r * p);  // + st*k
-            const uint32_t sm = st * m;
-            const uint32_t tb = p * st;            // twiddle index step per k
+            const uint32_t tb = p * st * sc;       // twiddle index step per k
             if (r == 4) {
                 const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
                 const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
@@ -60,14 +62,10 @@ DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *t
                 const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
                 const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
                 const float2 t3 = make_float2(d.y, -d.x);  // d * (-i)
-                const float2 b0 = make_float2(t0.x + t2.x, t0.y + t2.y);
-                const float2 b1 = make_float2(t1.x + t3.x, t1.y + t3.y);
-                const float2 b2 = make_float2(t0.x - t2.x, t0.y - t2.y);
-                const float2 b3 = make_float2(t1.x - t3.x, t1.y - t3.y);
-                Y[ob] = b0;
-                Y[ob + st] = cmul_conj_tw(b1, tw[tb]);
-                Y[ob + 2 * st] = cmul_conj_tw(b2, tw[2 * tb]);
-                Y[ob + 3 * st] = cmul_conj_tw(b3, tw[3 * tb]);
+                Y[ob] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(t1.x + t3.x, t1.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmul_conj_tw(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * tb]);
+                Y[ob + 3 * st] = cmul_conj_tw(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * tb]);
             } else if (r == 2) {
                 const float2 a0 = X[ib], a1 = X[ib + sm];
                 Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
@@ -92,6 +90,25 @@ DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *t
     return X;
 }
 
+// Real input, even L = 2M: the packed signal z[j] = g[2j] + i g[2j+1] went through one complex FFT
+// of length M (Z).  Bins 0..M of the length-L transform of g:
+//   X[k] = (Z[k] + conj Z[M-k]) / 2  +  w_L^k * (-i/2) (Z[k] - conj Z[M-k])
+template <int W>
+DEVI void fft_untangle(const DevPlan &P, const float2 *Z, float2 *out, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    const uint32_t M = P.M;
+    for (uint32_t k = threadIdx.x; k <= M; k += T) {
+        const float2 zk = Z[k == M ? 0 : k];
+        const float2 zm = Z[k == 0 ? 0 : M - k];
+        const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);   // Z[k] + conj Z[M-k]
+        const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);   // Z[k] - conj Z[M-k]
+        const float2 t = cmul_conj_tw(make_float2(b.y, -b.x), tw[k]);  // w^k * (-i b)
+        out[k] = make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+    }
+    __syncthreads();
+}
+
 // O(n^2) transform for n < 128 (any n, primes included).  f64 accumulation, f32 result.
 template <int W>
 DEVI void dft_direct(const DevPlan &P, const double *xs, float2 *out, const float2 *tw)
@@ -114,6 +131,40 @@ DEVI void dft_direct(const DevPlan &P, const double *xs, float2 *out, const floa
     __syncthreads();
 }
 
+// Sort of RLE run records rec = (start << 16 | end) by (bits of the run value xs[end], start):
+// the BTreeMap<u64, Vec<usize>> order of rle.rs:146-182.  Ascending-only bitonic network.
+template <int W>
+DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint32_t P2)
+{
+    constexpr int T = 64 * W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t npairs = P2 >> 1;
+    auto ce = [&](uint32_t i, uint32_t l) {
+        if (l < count) {
+            const uint32_t ra = rec[i], rb = rec[l];
+            const uint64_t ka = (uint64_t)__double_as_longlong(xs[ra & 0xffffu]);
+            const uint64_t kb = (uint64_t)__double_as_longlong(xs[rb & 0xffffu]);
+            if (ka > kb || (ka == kb && ra > rb)) { rec[i] = rb; rec[l] = ra; }
+        }
+    };
+    uint32_t lk = 1;
+    for (uint32_t k = 2; k <= P2; k <<= 1, ++lk) {
+        const uint32_t half = k >> 1;
+        for (uint32_t t = tid; t < npairs; t += T) {
+            const uint32_t i = ((t >> (lk - 1)) << lk) | (t & (half - 1));
+            ce(i, i ^ (k - 1));
+        }
+        __syncthreads();
+        for (uint32_t j = half >> 1; j >= 1; j >>= 1) {
+            for (uint32_t t = tid; t < npairs; t += T) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                ce(i, i | j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // the frame kernel
 // --------------------------------------------------------------------------------------------
@@ -134,8 +185,9 @@ __global__ __launch_bounds__(64 * W) void k_compress(
 
     double *xs = (double *)(smem + P.o_xs);
     float2 *tw = (float2 *)(smem + P.o_tw);
-    float2 *A = (float2 *)(smem + P.o_a);
-    float2 *B = (float2 *)(smem + P.o_b);
+    unsigned char *AB = smem + P.o_ab;
+    float2 *A = (float2 *)AB;
+    float2 *B = (float2 *)(AB + P.ab_half);
     Sel *sel = (Sel *)(smem + P.o_sel);
     uint32_t *aux = (uint32_t *)(smem + P.o_aux);
     double *red = (double *)(smem + P.o_red);
@@ -160,51 +212,33 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     }
     __syncthreads();
 
-    // ---- stats: min/max keep the first occurrence (strict compares, utils.rs:56-63) --------
+    // ---- stats (optimizer/utils.rs:39-89): min / max are the FIRST occurrence of the extreme
+    // value (strict compares), so +0.0 / -0.0 resolve as the sequential scan does ---------------
     double smin, smax;
     uint32_t bitdepth;
     {
         const double x0 = xs[0];
         double mn = x0, mx = x0;
-        uint32_t mni = 0, mxi = 0, fr_any = 0;
+        uint32_t fr_any = 0;
         for (uint32_t j = tid; j < n; j += T) {
             const double v = xs[j];
-            int64_t ip;
-            bool fz;
-            split_n(v, ip, fz);
-            fr_any |= fz ? 1u : 0u;
-            if (v > mx) { mx = v; mxi = j; }
-            if (v < mn) { mn = v; mni = j; }
+            fr_any |= frac_nonzero(v) ? 1u : 0u;
+            if (v > mx) mx = v;
+            if (v < mn) mn = v;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const double omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
-            const uint32_t omni = __shfl_xor(mni, o), omxi = __shfl_xor(mxi, o);
-            if (omn < mn || (omn == mn && omni < mni)) { mn = omn; mni = omni; }
-            if (omx > mx || (omx == mx && omxi < mxi)) { mx = omx; mxi = omxi; }
-            fr_any |= __shfl_xor(fr_any, o);
+        mn = block_minmax_f64<W, true>(mn, red, parity);
+        mx = block_minmax_f64<W, false>(mx, red, parity);
+        uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double v = xs[j];
+            if (v == mn) mni = min(mni, j);
+            if (v == mx) mxi = min(mxi, j);
         }
-        if (W > 1) {
-            // cross-wave combine through LDS (A is free here)
-            double *rv = (double *)A;
-            uint32_t *ri = (uint32_t *)(rv + 2 * W);
-            if ((tid & 63) == 0) {
-                const uint32_t w = tid >> 6;
-                rv[2 * w] = mn; rv[2 * w + 1] = mx;
-                ri[3 * w] = mni; ri[3 * w + 1] = mxi; ri[3 * w + 2] = fr_any;
-            }
-            __syncthreads();
-            mn = rv[0]; mx = rv[1]; mni = ri[0]; mxi = ri[1]; fr_any = ri[2];
-            for (int w = 1; w < W; ++w) {
-                const double omn = rv[2 * w], omx = rv[2 * w + 1];
-                const uint32_t omni = ri[3 * w], omxi = ri[3 * w + 1];
-                if (omn < mn || (omn == mn && omni < mni)) { mn = omn; mni = omni; }
-                if (omx > mx || (omx == mx && omxi < mxi)) { mx = omx; mxi = omxi; }
-                fr_any |= ri[3 * w + 2];
-            }
-            __syncthreads();
-        }
-        smin = mn; smax = mx;
+        mni = block_min_u32<W>(mni, red, parity);
+        mxi = block_min_u32<W>(mxi, red, parity);
+        fr_any = block_or_u32<W>(fr_any, red, parity);
+        smin = (mni < n) ? xs[mni] : x0;  // x0 NaN: nothing compares, the scan keeps data[0]
+        smax = (mxi < n) ? xs[mxi] : x0;
         int64_t maxi, mini;
         bool fz;
         split_n(smax, maxi, fz);
@@ -212,6 +246,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         bitdepth = fr_any ? 0u : bitdepth_of(maxi, mini);
     }
 
+    if (prm.debug_stop == 1) return;
     atsc_frame_diag dg;
     dg.fft_size = dg.poly_size = dg.rle_size = 0xFFFFFFFFu;
     dg.fft_trips = dg.fft_k = dg.poly_trips = dg.poly_step = 0;
@@ -251,6 +286,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         return;
     }
 
+    if (prm.debug_stop == 2) return;
     // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T
     double g[SPL], inv[SPL];
 #pragma unroll
@@ -267,6 +303,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
     }
 
+    if (prm.debug_stop == 3) return;
     // =========================================================================================
     // FFT candidate: fft.rs:288-362
     // =========================================================================================
@@ -283,6 +320,17 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             if (P.direct) {
                 dft_direct<W>(P, xs, A, tw);
                 spec = A;
+            } else if (P.half) {
+                float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) Af[j] = (float)g[m];
+                }
+                __syncthreads();
+                float2 *Z = fft_forward<W>(P, A, B, tw);
+                spec = (Z == A) ? B : A;
+                fft_untangle<W>(P, Z, spec, tw);
             } else {
 #pragma unroll
                 for (int m = 0; m < SPL; ++m) {
@@ -292,6 +340,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 __syncthreads();
                 spec = fft_forward<W>(P, A, B, tw);
             }
+            if (prm.debug_stop == 4) return;
             // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
             // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
             // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
@@ -324,12 +373,14 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
             if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
 
+            if (prm.debug_stop == 5) return;
             float acc[SPL];
 #pragma unroll
             for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
             float dc = 0.0f;
             const double mxd = (double)mxf, mnd = (double)mnf;
             const double Ld = (double)L;
+            const double invL = 1.0 / Ld;
             const uint32_t magicL = P.magicL;
             uint32_t used = 0, jump = 0, big = 0;
             double cur = prm.max_err + 1.0;
@@ -357,10 +408,11 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                     const float2 z = spec[pos];
                     if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
                     big += (pos >= 251) ? 1u : 0u;
-                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once
-                    const double cf = (pos == 0 || 2 * pos == L) ? 1.0 : 2.0;
-                    const float a = (float)(cf * (double)z.x / Ld);
-                    const float b = (float)(cf * (double)z.y / Ld);
+                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
+                    // the 1/L of fft.rs:343 is folded into the coefficient
+                    const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
+                    const float a = (float)(cf * (double)z.x);
+                    const float b = (float)(cf * (double)z.y);
                     if (pos == 0) {
                         dc = a;
                     } else {
@@ -398,12 +450,13 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             fft_err = cur;
             fft_k = used;
             fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
-            __syncthreads();  // sel[] is complete; A/B may be reused from here on
+            __syncthreads();  // sel[] is complete; AB may be reused from here on
         }
         dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
         dg.fft_err = fft_err;
     }
 
+    if (prm.debug_stop == 6) return;
     // =========================================================================================
     // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
     // =========================================================================================
@@ -417,7 +470,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         } else {
             const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
             const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
-            double2 *mm = (double2 *)A;  // per-segment Hermite tangents (m0, m1); A|B is free here
+            double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
             double cur = prm.max_err + 1.0;
             uint32_t jump = 0;
             while (prm.poly_target < round(cur * 10000.0) / 10000.0) {
@@ -430,13 +483,18 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 poly_K = K;
                 if (step > 1) {
                     // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
-                    // the first and the last two (polynomial.rs:349-353).  The tangents of a segment
-                    // are the same for all its samples: compute them once per segment, in the
-                    // crate's operation order (oracle: cubic_hermite).
+                    // the first and the last one (polynomial.rs:349-353).  Everything that is the
+                    // same for all samples of a segment (the tangents m0, m1) or for all samples at
+                    // the same offset r inside a segment (the four Hermite basis values) is computed
+                    // once, in the crate's operation order (oracle: cubic_hermite), so each sample's
+                    // value keeps the oracle's bits.
                     const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
                     const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
                     const double stepd = (double)step, gapLd = (double)gapL;
                     const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                    const uint32_t mm_bytes = (16 * K + 15) & ~15u;
+                    const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= P.ab_bytes);
+                    double4 *hb = (double4 *)(AB + mm_bytes);  // basis (h00, h10, h01, h11) per offset r
                     __syncthreads();
                     for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
                         const uint32_t t0i = sg * step;
@@ -449,6 +507,22 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                         t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
                         t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
                         mm[sg] = t;
+                    }
+                    if (use_tab) {
+                        for (uint32_t r = tid; r < step; r += T) {
+                            const double nt = div_small((double)r, stepd, ry);
+                            const double t2 = nt * nt;
+                            const double t3 = t2 * nt;
+                            const double two_t3 = t3 * 2.0;
+                            const double two_t2 = t2 * 2.0;
+                            const double three_t2 = t2 * 3.0;
+                            double4 h;
+                            h.x = two_t3 - three_t2 + 1.0;
+                            h.y = t3 - two_t2 + nt;
+                            h.z = three_t2 - two_t3;
+                            h.w = t3 - t2;
+                            hb[r] = h;
+                        }
                     }
                     __syncthreads();
                     double s = 0.0;
@@ -466,19 +540,25 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                                 const uint32_t t0i = sg * step;
                                 const bool last = (sg == K - 2);
                                 const uint32_t t1i = last ? (n - 1) : t0i + step;
-                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
-                                                            last ? ryL : ry);
                                 const double v0 = xs[t0i], v1 = xs[t1i];
-                                if (sg > 0 && K - sg > 2) {
+                                if (sg > 0 && !last) {  // Catmull-Rom: sg in 1..K-3
                                     const double2 t = mm[sg];
-                                    const double t2 = nt * nt;
-                                    const double t3 = t2 * nt;
-                                    const double two_t3 = t3 * 2.0;
-                                    const double two_t2 = t2 * 2.0;
-                                    const double three_t2 = t2 * 3.0;
-                                    sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
-                                         v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
+                                    if (use_tab) {
+                                        const double4 h = hb[i - t0i];
+                                        sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
+                                    } else {
+                                        const double nt = div_small((double)(i - t0i), stepd, ry);
+                                        const double t2 = nt * nt;
+                                        const double t3 = t2 * nt;
+                                        const double two_t3 = t3 * 2.0;
+                                        const double two_t2 = t2 * 2.0;
+                                        const double three_t2 = t2 * 3.0;
+                                        sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
+                                             v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
+                                    }
                                 } else {
+                                    const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                                last ? ryL : ry);
                                     sv = v0 * (1.0 - nt) + v1 * nt;
                                 }
                             }
@@ -515,51 +595,52 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
     }
 
+    if (prm.debug_stop == 7) return;
     // =========================================================================================
     // RLE candidate: rle.rs:142-189.  Exact size only when it can still win.
     // =========================================================================================
     const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
     uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0;
     bool rle_sorted = false;
-    uint64_t *rkeys = (uint64_t *)A;            // 8n <= 8L bytes
-    uint32_t *rstart = (uint32_t *)B;           // 4n
-    uint32_t *rends = rstart + n;               // 4n  (later: group head positions hp[])
+    uint32_t *rrec = (uint32_t *)AB;            // 4n: run records (start << 16 | end), n <= 4096
+    uint32_t *rhp = rrec + n;                   // 4n+4: group head positions hp[0..D]
     uint32_t *rps = (uint32_t *)tw;             // 4n  prefix of index varint bytes
     uint32_t *rph = rps + n;                    // 4n  prefix of group header bytes
     uint32_t rle_ib = 0;
+    auto run_key = [&](uint32_t rec) { return (uint64_t)__double_as_longlong(xs[rec & 0xffffu]); };
     // Sorts the runs by (value bits, start) = BTreeMap order (rle.rs:146,158-169,180-182) and sizes
-    // the groups.  Leaves: rkeys/rstart sorted, aux[i] = heads before i, rends[g] = head index of
-    // group g (rends[D] = R), rph[g] = header bytes of group g.
+    // the groups.  Leaves: rrec sorted, aux[i] = heads before i, rhp[g] = index of the first run of
+    // group g (rhp[D] = R), rph[g] = header bytes of group g.
     auto rle_sort_and_group = [&]() {
         __syncthreads();
         for (uint32_t j = tid; j < n; j += T)
             aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;  // run ends (rle.rs:154)
         __syncthreads();
         const uint32_t R = block_excl_scan<W>(aux, n, wsum);
+        uint32_t *ends = rhp;  // scratch until the groups are built
         for (uint32_t j = tid; j < n; j += T)
-            if (j + 1 >= n || xs[j + 1] != xs[j]) rends[aux[j]] = j;
+            if (j + 1 >= n || xs[j + 1] != xs[j]) ends[aux[j]] = j;
         __syncthreads();
         for (uint32_t r = tid; r < R; r += T) {
-            rkeys[r] = (uint64_t)__double_as_longlong(xs[rends[r]]);
-            rstart[r] = r ? rends[r - 1] + 1 : 0;
+            const uint32_t st = r ? ends[r - 1] + 1 : 0;
+            rrec[r] = (st << 16) | ends[r];
         }
         __syncthreads();
         uint32_t p2 = 1;
         while (p2 < R) p2 <<= 1;
-        block_sort<W, false>(rkeys, rstart, R, p2);
+        block_sort_runs<W>(rrec, xs, R, p2);
         for (uint32_t i = tid; i < R; i += T)
-            aux[i] = (i == 0 || rkeys[i] != rkeys[i - 1]) ? 1u : 0u;
+            aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
         __syncthreads();
         const uint32_t D = block_excl_scan<W>(aux, R, wsum);
         for (uint32_t i = tid; i < R; i += T)
-            if (i == 0 || rkeys[i] != rkeys[i - 1]) rends[aux[i]] = i;  // hp[g]
-        if (tid == 0) rends[D] = R;
+            if (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) rhp[aux[i]] = i;
+        if (tid == 0) rhp[D] = R;
         __syncthreads();
         uint32_t hb = 0;
         for (uint32_t gi = tid; gi < D; gi += T) {
-            const uint32_t h0 = rends[gi], h1 = rends[gi + 1];
-            const uint32_t b = value_bytes(bitdepth, __longlong_as_double((long long)rkeys[h0])) +
-                               vlen(h1 - h0);
+            const uint32_t h0 = rhp[gi], h1 = rhp[gi + 1];
+            const uint32_t b = value_bytes(bitdepth, xs[rrec[h0] & 0xffffu]) + vlen(h1 - h0);
             rph[gi] = b;
             hb += b;
         }
@@ -590,10 +671,10 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             if (R <= 64 || mode == ATSC_RLE) {
                 rle_sort_and_group();
             } else {
-                // Exact size without sorting: count distinct run values and their multiplicities in
-                // an LDS hash table (A|B is free: 4L slots of u32 run-end indices).
-                uint32_t *tab = (uint32_t *)A;
-                const uint32_t H = 4 * L;
+                // Exact size without sorting: count the distinct run values and their multiplicities
+                // in an LDS hash table (AB is free: ab_bytes / 4 >= 2n slots of run-end indices).
+                uint32_t *tab = (uint32_t *)AB;
+                const uint32_t H = P.ab_bytes >> 2;
                 __syncthreads();
                 for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
                 for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
@@ -626,6 +707,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         dg.rle_size = (mode == ATSC_RLE || lb < best_other) ? rle_size : 0xFFFFFFFEu;
     }
 
+    if (prm.debug_stop == 8) return;
     // =========================================================================================
     // selection: frame/mod.rs:113-147 (smallest passing payload, first of [FFT, Poly, RLE] on ties)
     // =========================================================================================
@@ -668,15 +750,25 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         out_len = hdr + body + 8;
     } else if (chosen == ATSC_POLYNOMIAL) {  // polynomial.rs:54-87
         const uint32_t hdr = 2 + vlen(poly_K);
-        for (uint32_t k = tid; k < poly_K; k += T) {
-            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
-            aux[k] = value_bytes(bitdepth, xs[t]);
-        }
-        __syncthreads();
-        const uint32_t body = block_excl_scan<W>(aux, poly_K, wsum);
-        for (uint32_t k = tid; k < poly_K; k += T) {
-            const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
-            put_value(out + hdr + aux[k], bitdepth, xs[t]);
+        uint32_t body;
+        if (bitdepth == 0 || bitdepth == 3) {
+            const uint32_t vbytes = bitdepth == 0 ? 8u : 1u;
+            body = poly_K * vbytes;
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                put_value(out + hdr + k * vbytes, bitdepth, xs[t]);
+            }
+        } else {
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                aux[k] = value_bytes(bitdepth, xs[t]);
+            }
+            __syncthreads();
+            body = block_excl_scan<W>(aux, poly_K, wsum);
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                put_value(out + hdr + aux[k], bitdepth, xs[t]);
+            }
         }
         if (tid == 0) {
             out[0] = 0;  // PolynomialType::Polynomial
@@ -688,26 +780,27 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         out_len = hdr + body + 17;
     } else {  // RLE: rle.rs:40-67
-        // records are sorted by (value bits, start); aux[i] = heads before i; rends = hp[]; rph = hb[]
+        // runs are sorted by (value bits, start); aux[i] = heads before i; rhp = hp[]; rph = hb[]
         if (!rle_sorted) rle_sort_and_group();
         const uint32_t R = rle_R, D = rle_D;
         const uint32_t hdr = 2 + vlen(D);
-        for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rstart[i]);
+        for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rrec[i] >> 16);
         __syncthreads();
         block_excl_scan<W>(rps, R, wsum);
         const uint32_t hb = block_excl_scan<W>(rph, D, wsum);
         uint32_t ibt = 0;
         for (uint32_t i = tid; i < R; i += T) {
-            const bool head = (i == 0 || rkeys[i] != rkeys[i - 1]);
+            const uint32_t rec = rrec[i], st = rec >> 16;
+            const bool head = (i == 0 || run_key(rec) != run_key(rrec[i - 1]));
             const uint32_t gi = head ? aux[i] : aux[i] - 1;
             const uint32_t ghb = (gi + 1 < D ? rph[gi + 1] : hb);  // header bytes up to and incl. gi
             if (head) {
                 uint8_t *p = out + hdr + rph[gi] + rps[i];
-                p += put_value(p, bitdepth, __longlong_as_double((long long)rkeys[i]));
-                put_varint(p, rends[gi + 1] - rends[gi]);
+                p += put_value(p, bitdepth, xs[rec & 0xffffu]);
+                put_varint(p, rhp[gi + 1] - rhp[gi]);
             }
-            put_varint(out + hdr + ghb + rps[i], rstart[i]);
-            if (i == R - 1) ibt = rps[i] + vlen(rstart[i]);
+            put_varint(out + hdr + ghb + rps[i], st);
+            if (i == R - 1) ibt = rps[i] + vlen(st);
         }
         ibt = block_sum_u32<W>(ibt, red, parity);
         if (tid == 0) {

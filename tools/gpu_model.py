@@ -71,6 +71,53 @@ def stockham_forward(x, L):
     return X
 
 
+def stockham_generic(X, M, L, rads):
+    """length-M Stockham (complex64) using the length-L table (tw index scaled by L/M)."""
+    c, s = twiddle_table(L)
+    sc = L // M
+    X = X.astype(np.complex64).copy(); Y = np.empty_like(X)
+    ncur, st = M, 1
+    h = np.float32(0.8660254037844386)
+    for r in rads:
+        m = ncur // r
+        for t in range(M // r):
+            q = t % st; p = t // st
+            a = [X[q + st * (p + m * j)] for j in range(r)]
+            if r == 2:
+                b = [a[0] + a[1], a[0] - a[1]]
+            elif r == 4:
+                t0, t1, t2 = a[0] + a[2], a[0] - a[2], a[1] + a[3]
+                d = a[1] - a[3]; t3 = np.complex64(complex(d.imag, -d.real))
+                b = [t0 + t2, t1 + t3, t0 - t2, t1 - t3]
+            else:
+                t1 = a[1] + a[2]; t2 = a[0] - np.complex64(0.5) * t1; d = a[1] - a[2]
+                t3 = np.complex64(complex(h * d.imag, -h * d.real))
+                b = [a[0] + t1, t2 + t3, t2 - t3]
+            for k in range(r):
+                idx = p * k * st * sc
+                w = np.complex64(complex(c[idx], -s[idx]))
+                Y[q + st * (r * p + k)] = b[k] * w if k else b[k]
+        X, Y = Y, X; ncur = m; st *= r
+    return X
+
+
+def real_fft_forward(g32, L):
+    """bins 0..L/2 of the DFT of the real f32 signal, via one complex FFT of length L/2."""
+    M = L // 2
+    z = (g32[0::2] + 1j * g32[1::2]).astype(np.complex64)
+    Z = stockham_generic(z, M, L, radices(M))
+    c, s = twiddle_table(L)
+    out = np.empty(M + 1, dtype=np.complex64)
+    half = np.float32(0.5)
+    for k in range(M + 1):
+        Zk = Z[k % M]; Zc = np.conj(Z[(M - k) % M])
+        a = np.complex64(Zk + Zc); b = np.complex64(Zk - Zc)
+        t = np.complex64(complex(b.imag, -b.real))
+        w = np.complex64(complex(c[k], -s[k]))
+        out[k] = np.complex64(half * a + half * np.complex64(w * t))
+    return out
+
+
 def flip_bitonic_sort(keys):
     """ascending-only bitonic network valid for any length (virtual +inf padding)."""
     a = list(keys)
@@ -115,7 +162,9 @@ def fft_ladder(x, max_err):
         g = np.concatenate([np.full(pre, x[0]), x, np.full(L - n - pre, x[-1])])
     else:
         L = n; pre = 0; g = x.copy()
-    if L >= 128:
+    if L >= 128 and L % 2 == 0:
+        X = np.concatenate([real_fft_forward(g.astype(np.float32), L), np.zeros(L - L // 2 - 1, dtype=np.complex64)])
+    elif L >= 128:
         X = stockham_forward(g.astype(np.float32).astype(np.complex64), L)
     else:
         X = np.fft.fft(g.astype(np.float32).astype(np.complex128)).astype(np.complex64)
