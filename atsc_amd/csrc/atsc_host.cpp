@@ -20,7 +20,7 @@ namespace atsc {
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
                                  const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                  const float2 *twpool, const KParams &prm, uint8_t *slots,
-                                 DevResult *res, atsc_frame_diag *diag, hipStream_t s);
+                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s);
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
@@ -65,6 +65,7 @@ struct atsc_plan {
     uint64_t n_frames = 0, n_samples = 0, body_bound = 0, slot_bytes = 0;
     PlanTables tabs;
     std::vector<uint32_t> class_count, class_lds, class_first;
+    std::vector<UniArgs> class_uni;  // per class: by-value launch arguments when the class is uniform
     DevFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
     DevResult *d_res = nullptr;
@@ -401,6 +402,32 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
         std::vector<uint32_t> cur(p->class_first);
         for (uint64_t f = 0; f < n_frames; ++f) ids[cur[cls[f]]++] = (uint32_t)f;
     }
+    // uniform classes: one frame length, frames and slots in arithmetic progression
+    p->class_uni.assign(N_CLASSES, UniArgs());
+    for (int c = 0; c < N_CLASSES; ++c) {
+        UniArgs &u = p->class_uni[c];
+        memset(&u, 0, sizeof(u));
+        const uint32_t cnt = p->class_count[c];
+        if (!cnt) continue;
+        const uint32_t *cid = ids.data() + p->class_first[c];
+        const DevFrame &f0 = frames[cid[0]];
+        const uint64_t stride = (atsc_payload_bound_bytes(f0.n) + 15) & ~15ull;
+        bool ok = true;
+        for (uint32_t i = 0; i < cnt && ok; ++i) {
+            const DevFrame &f = frames[cid[i]];
+            ok = cid[i] == cid[0] + i && f.plan == f0.plan &&
+                 f.sample_off == f0.sample_off + (uint64_t)i * f0.n &&
+                 f.slot_off == f0.slot_off + (uint64_t)i * stride;
+        }
+        if (ok) {
+            u.enabled = 1;
+            u.fid0 = cid[0];
+            u.sample_off0 = f0.sample_off;
+            u.slot_off0 = f0.slot_off;
+            u.slot_stride = stride;
+            u.plan = p->tabs.plans[f0.plan];
+        }
+    }
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_plan_destroy(p); return rc; }
     const uint32_t nb = (uint32_t)((n_frames + 1023) / 1024);
@@ -455,6 +482,18 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     prm.max_err = (double)max_error;  // frame/mod.rs:67,118: `max_error as f64`
     prm.poly_target = std::round(prm.max_err * 1000.0) / 1000.0;  // polynomial.rs:230
     {
+        // round_f64(err, 4) = round(err * 1e4) / 1e4 is monotone in the integer q = round(err * 1e4),
+        // so the loop tests of polynomial.rs:231,255 become integer threshold tests (no divide per trip)
+        const double t = prm.poly_target;
+        double q = std::floor(t * 10000.0) + 2.0;
+        while (q / 10000.0 > t) q -= 1.0;
+        prm.poly_q_hi = q;
+        q = std::floor(t * 10000.0) - 2.0;
+        while (q / 10000.0 < t) q += 1.0;
+        prm.poly_q_lo = q;
+        if (!(t == t)) { prm.poly_q_hi = INFINITY; prm.poly_q_lo = -INFINITY; }
+    }
+    {
         const double v = prm.max_err * 1000.0;  // fft.rs:334 `as i32` saturates, NaN -> 0
         prm.max_err_m = (v != v) ? 0 : v >= 2147483647.0 ? INT32_MAX : v <= -2147483648.0 ? INT32_MIN : (int32_t)v;
     }
@@ -492,7 +531,7 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         hipError_t e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
                                              plan->d_frames, plan->d_ids + plan->class_first[c],
                                              plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
-                                             plan->d_res, d_diag, s);
+                                             plan->d_res, d_diag, plan->class_uni[c], s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
         if (timed) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].second, s));

@@ -48,11 +48,26 @@ struct DevResult {
 struct KParams {
     double max_err;      // (double)(float) max_error
     double poly_target;  // round_f64(max_err, 3)  (polynomial.rs:230)
+    double poly_q_hi;    // largest integer q with q / 10000.0 <= poly_target:  target < round(err,4)  <=>  round(err*1e4) > q_hi
+    double poly_q_lo;    // smallest integer q with q / 10000.0 >= poly_target: target > round(err,4)  <=>  round(err*1e4) < q_lo
     int32_t max_err_m;   // (max_err * 1000.0) as i32  (fft.rs:334)
     int32_t mode;        // ATSC_* compressor id
     int32_t bounded;
     int32_t want_diag;
     int32_t debug_stop;  // profiling aid: leave the kernel after phase N (0 = run everything)
+};
+
+// Uniform launch: every frame of the class has the same length and frame f of the class sits at
+// sample_off0 + f*n with its slot at slot_off0 + f*slot_stride.  The per-length table then travels
+// by value in the kernel arguments, which removes the ids -> frames -> plans dependent loads from
+// the start of every workgroup.
+struct UniArgs {
+    uint32_t enabled;
+    uint32_t fid0;
+    uint64_t sample_off0;
+    uint64_t slot_off0;
+    uint64_t slot_stride;
+    DevPlan plan;
 };
 
 // parsed frame record for decompression

@@ -173,14 +173,24 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
     const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
-    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag)
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, const UniArgs uni)
 {
     constexpr int T = 64 * W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t fid = ids[blockIdx.x];
-    const DevFrame fr = frames[fid];
-    const DevPlan &P = plans[fr.plan];
+    uint32_t fid;
+    DevFrame fr;
+    if (uni.enabled) {
+        fid = uni.fid0 + blockIdx.x;
+        fr.sample_off = uni.sample_off0 + (uint64_t)blockIdx.x * uni.plan.n;
+        fr.slot_off = uni.slot_off0 + (uint64_t)blockIdx.x * uni.slot_stride;
+        fr.n = uni.plan.n;
+        fr.plan = 0;
+    } else {
+        fid = ids[blockIdx.x];
+        fr = frames[fid];
+    }
+    const DevPlan &P = uni.enabled ? uni.plan : plans[fr.plan];
     const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins;
 
     double *xs = (double *)(smem + P.o_xs);
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
             double cur = prm.max_err + 1.0;
             uint32_t jump = 0;
-            while (prm.poly_target < round(cur * 10000.0) / 10000.0) {
+            while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
                 ++poly_trips;
                 const uint32_t pts = base + jump;
                 const uint32_t step = max(n / pts, 1u);
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 }
                 if (poly_trips <= 17) jump += dj1;
                 else if (poly_trips <= 22) jump += dj2;
-                else if (prm.poly_target > round(cur * 10000.0) / 10000.0) break;
+                else if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
                 else { poly_step = 1; poly_K = n; cur = 0.0; break; }
                 if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
             }
@@ -880,7 +890,10 @@ __global__ __launch_bounds__(256) void k_pack_scan2(uint64_t *__restrict__ block
     if (threadIdx.x == 0) blocksum[nb] = carry;
 }
 
-// one wavefront per frame: header varints + payload copy; also the user-visible side arrays
+// one wavefront per frame: header varints + payload copy; also the user-visible side arrays.
+// FUSED: blocksum[] still holds the per-chunk totals (k_pack_scan2 was skipped, at most 64 chunks);
+// every wavefront adds up the totals of the chunks before its own.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_pack_emit(
     const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
     const uint32_t *__restrict__ local, const uint64_t *__restrict__ blocksum,
@@ -892,7 +905,17 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     if (f >= n_frames) return;
     const DevFrame fr = frames[f];
     const DevResult r = res[f];
-    const uint64_t off = blocksum[f / PACK_CHUNK] + local[f];
+    const uint32_t chunk = (uint32_t)(f / PACK_CHUNK);
+    uint64_t base;
+    if (FUSED) {
+        const uint64_t v = lane < chunk ? blocksum[lane] : 0;
+        const uint32_t lo = wave_sum_u32((uint32_t)(v & 0xffffffu));
+        const uint32_t hi = wave_sum_u32((uint32_t)(v >> 24));
+        base = (uint64_t)lo + ((uint64_t)hi << 24);
+    } else {
+        base = blocksum[chunk];
+    }
+    const uint64_t off = base + local[f];
     const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
     if (lane == 0) {
         rec_off[f] = off;
@@ -920,7 +943,7 @@ template <int W, int SPL>
 static hipError_t launch_class(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
-                               DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
     auto kern = k_compress<W, SPL>;
@@ -930,22 +953,22 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, samples, frames, ids, plans, twpool,
-                       prm, slots, res, diag);
+                       prm, slots, res, diag, uni);
     return hipGetLastError();
 }
 
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
                                  const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                  const float2 *twpool, const KParams &prm, uint8_t *slots,
-                                 DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
 {
     switch (cls) {
-    case 0: return launch_class<1, 2>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
-    case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
-    case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
-    case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
-    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
-    case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, s);
+    case 0: return launch_class<1, 2>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -958,9 +981,15 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
-    hipLaunchKernelGGL(k_pack_scan2, dim3(1), dim3(256), 0, s, blocksum, nb);
-    hipLaunchKernelGGL(k_pack_emit, dim3((uint32_t)((n_frames + 3) / 4)), dim3(256), 0, s, frames,
-                       res, n_frames, local, blocksum, slots, body, body_cap, rec_off, chosen, err);
+    const dim3 eg((uint32_t)((n_frames + 3) / 4));
+    if (nb <= 64) {
+        hipLaunchKernelGGL(k_pack_emit<true>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                           slots, body, body_cap, rec_off, chosen, err);
+    } else {
+        hipLaunchKernelGGL(k_pack_scan2, dim3(1), dim3(256), 0, s, blocksum, nb);
+        hipLaunchKernelGGL(k_pack_emit<false>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                           slots, body, body_cap, rec_off, chosen, err);
+    }
     return hipGetLastError();
 }
 

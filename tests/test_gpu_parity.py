@@ -278,3 +278,26 @@ def test_full_size_config2_10m(ctx, A):
     r = _full_size_roundtrip(ctx, A, 10485760, ME5, seed=0)
     _log("config 10M roundtrip %r" % r)
     assert len(r["codecs"]) >= 4
+
+
+def test_many_small_frames_two_level_pack(ctx, A, oracle):
+    """131072 frames of 8 samples: the direct-DFT class (n < 128) and the record packer's two-level
+    offset scan (more than 64 chunks of 1024 frames)."""
+    nf, fl = 131072, 8
+    x = H.synth_series(5, nf * fl, block=4096)
+    off = H.frame_offsets(len(x), fl)
+    rec, rec_off, chosen, err = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+    bro, cho, _ = oracle.stream_compress(x, off, oracle.AUTO, True, ME5, 0)
+    assert np.array_equal(chosen, cho)
+    body_off, n = A.bro_open(bro)
+    assert n == nf
+    ref = bro[body_off:]
+    assert len(rec) == len(ref)
+    fr_g = H.parse_bro_body(rec, with_count=False)
+    fr_o = H.parse_bro_body(ref, with_count=False)
+    bad = [i for i in range(nf) if fr_g[i] != fr_o[i] and fr_g[i][2] != oracle.FFT]
+    assert not bad, bad[:5]
+    nfft = sum(1 for f in fr_g if f[2] == oracle.FFT)
+    exact = sum(1 for i in range(nf) if fr_g[i] == fr_o[i])
+    _log("small frames: %d frames, %d fft, %d byte-identical" % (nf, nfft, exact))
+    assert np.all(np.diff(rec_off.astype(np.int64)) > 0)
