@@ -60,12 +60,25 @@ struct PlanTables {
     float2 *d_tw = nullptr;
 };
 
+// Trial launch of the sample-level selector: the first COMPRESSION_SPEED[level] samples of every
+// frame that is at least that long (frame/mod.rs:89-111).
+struct TrialPlan {
+    PlanTables tabs;
+    DevFrame *d_frames = nullptr;
+    uint32_t *d_ids = nullptr;
+    DevResult *d_res = nullptr;
+    uint32_t count = 0, lds = 0, min_n = 0;
+    int cls = 0;
+};
+
 struct atsc_plan {
     atsc_ctx *ctx = nullptr;
     uint64_t n_frames = 0, n_samples = 0, body_bound = 0, slot_bytes = 0;
     PlanTables tabs;
     std::vector<uint32_t> class_count, class_lds, class_first;
     std::vector<UniArgs> class_uni;  // per class: by-value launch arguments when the class is uniform
+    std::vector<DevFrame> h_frames;  // host copy (trial plans are derived from it)
+    mutable TrialPlan *trials[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
     DevResult *d_res = nullptr;
@@ -244,8 +257,7 @@ extern "C" const char *atsc_strerror(int rc)
     case ATSC_E_INVALID: return "invalid argument";
     case ATSC_E_NOMEM: return "out of memory";
     case ATSC_E_UNSUPPORTED:
-        return "not implemented on the GPU path yet (frames > 4096 samples, IDW, sample levels > 0, "
-               "unbounded fft/polynomial)";
+        return "not implemented on the GPU path yet (frames > 4096 samples, IDW, unbounded fft/polynomial)";
     case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case ATSC_E_HIP: return "HIP runtime error";
     case ATSC_E_CAPACITY: return "output buffer too small";
@@ -327,9 +339,20 @@ extern "C" int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t 
 // ------------------------------------------------------------------------------------------
 // compress plan
 // ------------------------------------------------------------------------------------------
+static void free_trial(TrialPlan *t)
+{
+    if (!t) return;
+    free_tables(t->tabs);
+    if (t->d_frames) (void)hipFree(t->d_frames);
+    if (t->d_ids) (void)hipFree(t->d_ids);
+    if (t->d_res) (void)hipFree(t->d_res);
+    delete t;
+}
+
 extern "C" void atsc_plan_destroy(atsc_plan *p)
 {
     if (!p) return;
+    for (int i = 0; i < 7; ++i) free_trial(p->trials[i]);
     free_tables(p->tabs);
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_ids) (void)hipFree(p->d_ids);
@@ -392,6 +415,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
         bound += pb + 16;
     }
     p->n_samples = frame_off[n_frames] - frame_off[0];
+    p->h_frames = frames;
     p->slot_bytes = slot;
     p->body_bound = bound;
     // frame ids grouped by class
@@ -419,7 +443,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
                  f.sample_off == f0.sample_off + (uint64_t)i * f0.n &&
                  f.slot_off == f0.slot_off + (uint64_t)i * stride;
         }
-        if (ok) {
+        if (ok && !getenv("ATSC_NO_UNIFORM")) {
             u.enabled = 1;
             u.fid0 = cid[0];
             u.sample_off0 = f0.sample_off;
@@ -452,6 +476,48 @@ extern "C" uint64_t atsc_plan_n_frames(const atsc_plan *p) { return p ? p->n_fra
 extern "C" uint64_t atsc_plan_n_samples(const atsc_plan *p) { return p ? p->n_samples : 0; }
 extern "C" uint64_t atsc_plan_body_bound(const atsc_plan *p) { return p ? p->body_bound : 0; }
 
+static const uint32_t COMPRESSION_SPEED[7] = {0x7fffffffu, 4096, 2048, 1024, 512, 256, 128};  // frame/mod.rs:22
+
+static int get_trial(atsc_ctx *ctx, const atsc_plan *plan, int level, TrialPlan **out)
+{
+    *out = nullptr;
+    if (plan->trials[level]) { *out = plan->trials[level]; return ATSC_OK; }
+    const uint32_t S = COMPRESSION_SPEED[level];
+    TrialPlan *t = new (std::nothrow) TrialPlan();
+    if (!t) return ATSC_E_NOMEM;
+    t->min_n = S;
+    std::vector<DevFrame> fr(plan->h_frames);
+    std::vector<uint32_t> ids;
+    for (size_t f = 0; f < fr.size(); ++f)
+        if (fr[f].n >= S) ids.push_back((uint32_t)f);
+    t->count = (uint32_t)ids.size();
+    if (t->count) {
+        std::map<uint32_t, uint64_t> tw_by_L;
+        int rc = build_plan_entry(S, t->tabs, tw_by_L);
+        if (rc) { free_trial(t); return fail(ctx, rc, "trial plan entry"); }
+        const DevPlan &dp = t->tabs.plans[0];
+        t->cls = class_of(S, dp.L);
+        t->lds = dp.lds_bytes;
+        for (uint32_t id : ids) { fr[id].n = S; fr[id].plan = 0; }
+        rc = upload_tables(ctx, t->tabs);
+        if (rc) { free_trial(t); return rc; }
+#define TCHK(call)                                                                      \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) { free_trial(t); return fail(ctx, ATSC_E_HIP, #call, e__); } \
+    } while (0)
+        TCHK(hipMalloc((void **)&t->d_frames, fr.size() * sizeof(DevFrame)));
+        TCHK(hipMemcpy(t->d_frames, fr.data(), fr.size() * sizeof(DevFrame), hipMemcpyHostToDevice));
+        TCHK(hipMalloc((void **)&t->d_ids, ids.size() * sizeof(uint32_t)));
+        TCHK(hipMemcpy(t->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        TCHK(hipMalloc((void **)&t->d_res, fr.size() * sizeof(DevResult)));
+#undef TCHK
+    }
+    plan->trials[level] = t;
+    *out = t;
+    return ATSC_OK;
+}
+
 extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
                                       int compressor, int bounded, float max_error, int sample_level,
                                       uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
@@ -462,7 +528,6 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     switch (compressor) {
     case ATSC_AUTO:
         if (!bounded) return fail(ctx, ATSC_E_INVALID, "compress: Auto needs the bounded path (compressor/mod.rs:72 todo!())");
-        if (sample_level != 0) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: sample level > 0");
         break;
     case ATSC_FFT:
     case ATSC_POLYNOMIAL:
@@ -512,6 +577,26 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         ctx->diag_n = plan->n_frames;
         ctx->diag_stream = s;
         d_diag = ctx->d_diag;
+    }
+    prm.trial = 0;
+    prm.trial_min_n = 0;
+    prm.trial_res = nullptr;
+    if (compressor == ATSC_AUTO && sample_level > 0) {
+        TrialPlan *t = nullptr;
+        int rc = get_trial(ctx, plan, sample_level, &t);
+        if (rc) return rc;
+        if (t->count) {
+            KParams tp = prm;
+            tp.trial = 1;
+            UniArgs nouni;
+            memset(&nouni, 0, sizeof(nouni));
+            hipError_t e = launch_compress_class(t->cls, t->count, t->lds, d_samples, t->d_frames, t->d_ids,
+                                                 t->tabs.d_plans, t->tabs.d_tw, tp, plan->d_slots, t->d_res,
+                                                 nullptr, nouni, s);
+            if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress (trial)", e);
+            prm.trial_res = t->d_res;
+            prm.trial_min_n = t->min_n;
+        }
     }
     int dominant = 0;
     for (int c = 1; c < N_CLASSES; ++c)

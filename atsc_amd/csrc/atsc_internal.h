@@ -55,6 +55,11 @@ struct KParams {
     int32_t bounded;
     int32_t want_diag;
     int32_t debug_stop;  // profiling aid: leave the kernel after phase N (0 = run everything)
+    // sample-level selection (frame/mod.rs:89-111)
+    int32_t trial;               // 1: this launch is the trial on the frame prefixes: no Constant
+                                 //    shortcut, no payload emission, only res[].chosen matters
+    uint32_t trial_min_n;        // COMPRESSION_SPEED[level]; frames at least this long use the trial's codec
+    const DevResult *trial_res;  // results of the trial launch (indexed like the frames), or null
 };
 
 // Uniform launch: every frame of the class has the same length and frame f of the class sits at

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     int parity = 0;
 
     uint8_t *out = slots + fr.slot_off;
-    const int mode = prm.mode;
+    int mode = prm.mode;
 
     // ---- load samples + twiddles ----------------------------------------------------------
     {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     dg.fft_err = dg.poly_err = 0.0;
 
     // ---- Constant: frame/mod.rs:82-88 (auto shortcut) or forced (constant.rs:135-139) ------
-    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && smin == smax)) {
+    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && !prm.trial && smin == smax)) {
         if (tid == 0) {
             out[0] = 30;
             out[1] = (uint8_t)bitdepth;
@@ -295,6 +295,11 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         return;
     }
+
+    // frame/mod.rs:89-111: frames of at least COMPRESSION_SPEED[level] samples take the codec the
+    // trial on their first COMPRESSION_SPEED[level] samples chose, whatever error it then reaches
+    if (mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
+        mode = (int)prm.trial_res[fid].chosen;
 
     if (prm.debug_stop == 2) return;
     // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T
@@ -740,6 +745,14 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     // emit the chosen payload into the frame's slot
     // =========================================================================================
     uint32_t out_len = 0;
+    if (prm.trial) {
+        if (tid == 0) {
+            res[fid].err = chosen_err;
+            res[fid].len = 0;
+            res[fid].chosen = (uint32_t)chosen;
+        }
+        return;
+    }
     if (chosen == ATSC_FFT) {  // fft.rs:119-130
         const uint32_t hdr = 1 + vlen(fft_k);
         for (uint32_t i = tid; i < fft_k; i += T) aux[i] = vlen(sel[i].pos) + 8;

@@ -301,3 +301,22 @@ def test_many_small_frames_two_level_pack(ctx, A, oracle):
     exact = sum(1 for i in range(nf) if fr_g[i] == fr_o[i])
     _log("small frames: %d frames, %d fft, %d byte-identical" % (nf, nfft, exact))
     assert np.all(np.diff(rec_off.astype(np.int64)) > 0)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6])
+def test_sample_levels(ctx, A, oracle, level):
+    """-c / --compression-selection-sample-level (frame/mod.rs:89-111): frames at least
+    COMPRESSION_SPEED[level] long take the codec chosen on their prefix; shorter ones run the full
+    selector.  Mixed lengths so both branches and the constant shortcut are hit."""
+    sizes = [4096, 2048, 1024, 1000, 512, 300, 256, 200, 128, 100, 64]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes * 3):
+        klass = (k * 7) % 5
+        v = H.synth_series(300 + k, n, klass=klass)
+        if k % 11 == 3:  # constant prefix, non-constant tail: the trial must not take the shortcut
+            v[: n // 2] = v[0]
+        xs.append(v)
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, ME5, level=level)
+    _log(P.assert_summary(s, len(sizes) * 3, "sample level %d codecs %s" % (level, s["codecs"])))
