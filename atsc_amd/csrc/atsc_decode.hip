@@ -100,11 +100,13 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
             for (uint32_t i = 0; i < n && !r.bad; ++i) xs[i] = (double)unzig(rd_varint(r));
             break;
         }
+        case ATSC_IDW:
         case ATSC_POLYNOMIAL: {
             const uint32_t id = (uint32_t)rd_varint(r);
             const uint32_t bd = (uint32_t)rd_varint(r);
             const uint64_t cnt = rd_varint(r);
-            if (id != 0 || bd > 3 || cnt > n) r.bad = true;
+            if (id > 1 || bd > 3 || cnt > n) r.bad = true;
+            h.u2 = id;  // PolynomialType decides the interpolation (polynomial.rs:400-403), not the frame tag
             for (uint32_t i = 0; i < cnt && !r.bad; ++i) xs[i] = rd_value(r, bd);
             h.d0 = __longlong_as_double((long long)rd_le(r, 8));  // min
             h.d1 = __longlong_as_double((long long)rd_le(r, 8));  // max
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         for (uint32_t j = tid; j < n; j += T) out[j] = xs[j];
         return;
     }
-    if (fr.tag == ATSC_POLYNOMIAL) {
+    if (fr.tag == ATSC_POLYNOMIAL || fr.tag == ATSC_IDW) {
         const double mn = h.d0, mx = h.d1;
         if (mx == mn) {  // polynomial.rs:396-399
             for (uint32_t j = tid; j < n; j += T) out[j] = mx;
@@ -180,6 +182,25 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         }
         if (!ok) {  // a stream the reference's encoder cannot produce
             if (tid == 0) atomicExch(status, 1);
+            return;
+        }
+        if (h.u2 == 1) {  // idw_to_data: polynomial.rs:375-393
+            for (uint32_t j = tid; j < n; j += T) {
+                const double x = (double)j;
+                double num = 0.0, den = 0.0, sv = 0.0;
+                bool hit = false;
+                for (uint32_t k = 0; k < K && !hit; ++k) {
+                    const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                    const double d = fabs((double)pk - x);
+                    if (d == 0.0) { hit = true; sv = xs[k]; }
+                    else { const double w = 1.0 / (d * d); num += w * xs[k]; den += w; }
+                }
+                if (!hit) sv = num / den;
+                double o = round(sv * 100000.0) / 100000.0;
+                if (o < mn) o = mn;
+                else if (o > mx) o = mx;
+                out[j] = o;
+            }
             return;
         }
         const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;

@@ -257,7 +257,7 @@ extern "C" const char *atsc_strerror(int rc)
     case ATSC_E_INVALID: return "invalid argument";
     case ATSC_E_NOMEM: return "out of memory";
     case ATSC_E_UNSUPPORTED:
-        return "not implemented on the GPU path yet (frames > 4096 samples, IDW, unbounded fft/polynomial)";
+        return "not implemented on the GPU path yet (frames > 4096 samples, unbounded fft)";
     case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case ATSC_E_HIP: return "HIP runtime error";
     case ATSC_E_CAPACITY: return "output buffer too small";
@@ -530,15 +530,14 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         if (!bounded) return fail(ctx, ATSC_E_INVALID, "compress: Auto needs the bounded path (compressor/mod.rs:72 todo!())");
         break;
     case ATSC_FFT:
-    case ATSC_POLYNOMIAL:
-        if (!bounded) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: unbounded fft/polynomial");
+        if (!bounded) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: unbounded fft");
         break;
+    case ATSC_POLYNOMIAL:
+    case ATSC_IDW:
     case ATSC_NOOP:
     case ATSC_CONSTANT:
     case ATSC_RLE:
         break;
-    case ATSC_IDW:
-        return fail(ctx, ATSC_E_UNSUPPORTED, "compress: idw");
     default:
         return fail(ctx, ATSC_E_INVALID, "compress: unknown compressor id");
     }
@@ -805,7 +804,6 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
             return fail(ctx, ATSC_E_FORMAT, "dplan_create: truncated frame record");
         }
         if (tag > 6 || tag == ATSC_AUTO) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: compressor id"); }
-        if (tag == ATSC_IDW) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: idw frame"); }
         uint64_t nout = sc;
         if (tag == ATSC_NOOP) {
             // noop_to_data returns the stored vector whatever sample_count says (noop.rs:79-83)

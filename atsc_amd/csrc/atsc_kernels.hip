@@ -475,13 +475,21 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     // =========================================================================================
     // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
     // =========================================================================================
-    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
+    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL || mode == ATSC_IDW);
+    const bool idw = (mode == ATSC_IDW);  // polynomial.rs:29-34,202-207: same codec, other interpolation
     uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
     double poly_err = 0.0;
     if (run_poly) {
         if (smax == smin) {
             poly_K = 0;  // polynomial.rs:210-213
             poly_step = 1;
+        } else if (!prm.bounded) {
+            // Compressor::compress -> polynomial() -> compress_hinted(baseline points), no error loop
+            // (polynomial.rs:307-314,407-413)
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            poly_step = max(n / base, 1u);
+            const uint32_t cnt = (n + poly_step - 1) / poly_step;
+            poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
         } else {
             const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
             const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
@@ -496,7 +504,40 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
                 poly_step = step;
                 poly_K = K;
-                if (step > 1) {
+                if (step > 1 && idw) {
+                    // polynomial.rs:375-393 + inverse_distance_weight 0.1.1 (oracle: poly_idw_to_data):
+                    // every sample sums over ALL K points in ascending order; an exact hit returns the
+                    // point's value.  O(n K) per trip, forced `--compressor idw` only.
+                    double s = 0.0;
+#pragma unroll
+                    for (int m = 0; m < SPL; ++m) {
+                        const uint32_t j = tid + m * T;
+                        if (j >= pre && j < pre + n) {
+                            const double x = (double)(j - pre);
+                            double num = 0.0, den = 0.0, hitv = 0.0;
+                            bool hit = false;
+                            for (uint32_t k = 0; k < K; ++k) {
+                                const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                                const double v = xs[pk];
+                                const double d = fabs((double)pk - x);
+                                if (d == 0.0) {
+                                    if (!hit) { hit = true; hitv = v; }
+                                } else if (!hit) {
+                                    const double w = 1.0 / (d * d);
+                                    num += w * v;
+                                    den += w;
+                                }
+                            }
+                            const double sv = hit ? hitv : num / den;
+                            double o = div1e5(round(sv * 100000.0));
+                            if (o < smin) o = smin;
+                            else if (o > smax) o = smax;
+                            s += fabs(o - g[m]) * inv[m];
+                        }
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                } else if (step > 1) {
                     // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
                     // the first and the last one (polynomial.rs:349-353).  Everything that is the
                     // same for all samples of a segment (the tangents m0, m1) or for all samples at
@@ -738,7 +779,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         chosen_err = chosen == ATSC_FFT ? fft_err : chosen == ATSC_POLYNOMIAL ? poly_err : 0.0;
     } else {
         chosen = mode;
-        chosen_err = mode == ATSC_FFT ? fft_err : mode == ATSC_POLYNOMIAL ? poly_err : 0.0;
+        chosen_err = mode == ATSC_FFT ? fft_err : (mode == ATSC_POLYNOMIAL || mode == ATSC_IDW) ? poly_err : 0.0;
     }
 
     // =========================================================================================
@@ -771,7 +812,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             put_f32(out + hdr + body + 4, mnf);
         }
         out_len = hdr + body + 8;
-    } else if (chosen == ATSC_POLYNOMIAL) {  // polynomial.rs:54-87
+    } else if (chosen == ATSC_POLYNOMIAL || chosen == ATSC_IDW) {  // polynomial.rs:54-87
         const uint32_t hdr = 2 + vlen(poly_K);
         uint32_t body;
         if (bitdepth == 0 || bitdepth == 3) {
@@ -794,7 +835,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             }
         }
         if (tid == 0) {
-            out[0] = 0;  // PolynomialType::Polynomial
+            out[0] = idw ? 1 : 0;  // PolynomialType::{Polynomial, Idw}
             out[1] = (uint8_t)bitdepth;
             put_varint(out + 2, poly_K);
             put_f64(out + hdr + body, smin);

@@ -67,10 +67,10 @@ def test_auto_mixed_block(ctx, A, oracle):
     assert abs(s["bytes"] - s["oracle_bytes"]) <= 0.05 * s["oracle_bytes"]
 
 
-@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "RLE", "CONSTANT", "NOOP"])
+@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "IDW", "RLE", "CONSTANT", "NOOP"])
 def test_forced_codecs(ctx, A, oracle, comp):
     cid = getattr(A, comp)
-    bounded = comp in ("FFT", "POLYNOMIAL")  # main.rs:150-162
+    bounded = comp in ("FFT", "POLYNOMIAL", "IDW")  # main.rs:150-162
     x = np.concatenate([H.synth_series(5, 256 * 12, klass=k) for k in range(5)])
     off = H.frame_offsets(len(x), 256)
     s = P.compare_batch(oracle, ctx, x, off, cid, bounded, ME5)
@@ -170,12 +170,12 @@ def test_edge_frames_auto(ctx, A, oracle):
         _log(P.assert_summary(s, len(fr), "edge frames me=%r codecs %s" % (me, s["codecs"])))
 
 
-@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "RLE", "NOOP", "CONSTANT"])
+@pytest.mark.parametrize("comp", ["FFT", "POLYNOMIAL", "IDW", "RLE", "NOOP", "CONSTANT"])
 def test_edge_frames_forced(ctx, A, oracle, comp):
     fr = _edge_frames()
     x = np.concatenate(fr)
     off = H.frame_offsets(len(x), 256)
-    s = P.compare_batch(oracle, ctx, x, off, getattr(A, comp), comp in ("FFT", "POLYNOMIAL"), ME5)
+    s = P.compare_batch(oracle, ctx, x, off, getattr(A, comp), comp in ("FFT", "POLYNOMIAL", "IDW"), ME5)
     _log(P.assert_summary(s, len(fr), "edge forced %s" % comp))
 
 
@@ -186,8 +186,9 @@ def test_decompress_matches_oracle(ctx, A, oracle):
     x = np.concatenate([H.synth_series(21, 256 * 16, klass=k) for k in range(5)] + _edge_frames())
     off = H.frame_offsets(len(x), 256)
     nf = len(off) - 1
-    for comp, bounded in ((A.AUTO, True), (A.FFT, True), (A.POLYNOMIAL, True), (A.RLE, False),
-                          (A.NOOP, False), (A.CONSTANT, False)):
+    for comp, bounded in ((A.AUTO, True), (A.FFT, True), (A.POLYNOMIAL, True), (A.IDW, True),
+                          (A.RLE, False), (A.NOOP, False), (A.CONSTANT, False), (A.POLYNOMIAL, False),
+                          (A.IDW, False)):
         # decode the ORACLE's stream on the GPU and compare with the oracle's own decode
         bro, chosen, _ = oracle.stream_compress(x, off, comp, bounded, ME5, 0)
         ref = oracle.decompress_data(bro)
@@ -320,3 +321,52 @@ def test_sample_levels(ctx, A, oracle, level):
     x = np.concatenate(xs)
     s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, ME5, level=level)
     _log(P.assert_summary(s, len(sizes) * 3, "sample level %d codecs %s" % (level, s["codecs"])))
+
+
+@pytest.mark.parametrize("comp", ["POLYNOMIAL", "IDW"])
+def test_unbounded_compress(ctx, A, oracle, comp):
+    """CompressedStream::compress_chunk_with (data.rs:47-53) -> Compressor::compress
+    (compressor/mod.rs:63-74): polynomial()/idw store max(3, n/100) points, no error loop."""
+    xs, offs = [], [0]
+    for k, n in enumerate([12, 17, 100, 256, 300, 1024, 4096, 4, 256, 512]):
+        v = H.synth_series(400 + k, n, klass=k % 5)
+        xs.append(v)
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), getattr(A, comp), False, 0.0)
+    _log(P.assert_summary(s, 10, "unbounded %s" % comp))
+    assert s["exact"] == 10
+
+
+def test_reference_kat_vectors_on_gpu(ctx, A):
+    """The reference's own byte-level known-answer vectors, straight through the C ABI."""
+    from tests.golden import kat as K
+
+    def run(data, comp, bounded=False):
+        rec, _, _, _ = ctx.compress_host(np.array(data), [0, len(data)], comp, bounded, 0.0, 0)
+        (fs, sc, tag, payload), = H.parse_bro_body(rec, with_count=False)
+        assert (fs, sc, tag) == (41, len(data), comp)
+        return payload
+
+    for name in ("CONSTANT_U8", "CONSTANT_F64"):
+        d, want = getattr(K, name)
+        assert run(d, A.CONSTANT) == bytes(want)
+    assert run(K.NOOP[0], A.NOOP) == bytes(K.NOOP[1])
+    for name in ("RLE_CONSTANT", "RLE_SIMPLE", "RLE_U8", "RLE_F64"):
+        d, want = getattr(K, name)
+        assert run(d, A.RLE) == bytes(want)
+    for name in ("POLY_U8", "POLY_I16", "POLY_I32", "POLY_F64", "POLY_LINE"):
+        d, want = getattr(K, name)
+        assert run(d, A.POLYNOMIAL) == bytes(want)
+    for name in ("IDW_U8", "IDW_LINE"):
+        d, want = getattr(K, name)
+        assert run(d, A.IDW) == bytes(want)
+    # decoded values: polynomial.rs:486-514, :538-569
+    for name, comp in (("POLY_CR_OUT", A.POLYNOMIAL), ("POLY_LINEAR_OUT", A.POLYNOMIAL),
+                       ("IDW_OUT", A.IDW), ("IDW_LINEAR_OUT", A.IDW)):
+        d, want = getattr(K, name)
+        rec, _, _, _ = ctx.compress_host(np.array(d), [0, len(d)], comp, False, 0.0, 0)
+        assert list(ctx.decompress_host(rec)) == want
+    # data.rs:146-154 whole stream
+    rec, _, _, _ = ctx.compress_host(np.ones(1024), [0, 1024], A.CONSTANT, False, 0.0, 0)
+    assert A.bro_prefix(1) + rec == bytes(K.STREAM_CONSTANT_1024)
