@@ -60,15 +60,17 @@ struct PlanTables {
     float2 *d_tw = nullptr;
 };
 
-// Trial launch of the sample-level selector: the first COMPRESSION_SPEED[level] samples of every
-// frame that is at least that long (frame/mod.rs:89-111).
-struct TrialPlan {
+// A second view of the same batch with other per-frame transform parameters:
+//  * trial launch of the sample-level selector: the first COMPRESSION_SPEED[level] samples of every
+//    frame that is at least that long (frame/mod.rs:89-111)
+//  * FFT::compress (unbounded): no Gibbs padding, transform length = frame length (fft.rs:366-388)
+struct SubPlan {
     PlanTables tabs;
     DevFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
     DevResult *d_res = nullptr;
-    uint32_t count = 0, lds = 0, min_n = 0;
-    int cls = 0;
+    std::vector<uint32_t> class_count, class_lds, class_first;
+    uint32_t count = 0, min_n = 0;
 };
 
 struct atsc_plan {
@@ -78,7 +80,8 @@ struct atsc_plan {
     std::vector<uint32_t> class_count, class_lds, class_first;
     std::vector<UniArgs> class_uni;  // per class: by-value launch arguments when the class is uniform
     std::vector<DevFrame> h_frames;  // host copy (trial plans are derived from it)
-    mutable TrialPlan *trials[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    mutable SubPlan *trials[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    mutable SubPlan *nopad = nullptr;
     DevFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
     DevResult *d_res = nullptr;
@@ -158,19 +161,22 @@ static int class_of(uint32_t n, uint32_t L)
 }
 
 // Fills the per-length table entry (see DevPlan) and appends the twiddle table of L if new.
-static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64_t> &tw_by_L)
+static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64_t> &tw_by_L,
+                            bool nopad = false)
 {
     DevPlan p;
     memset(&p, 0, sizeof(p));
     p.n = n;
-    if (n >= 128) {  // fft.rs:305-309
+    if (n >= 128 && !nopad) {  // fft.rs:305-309
         p.L = (uint32_t)atsc_next_size(n);
         p.pre = (p.L - n) / 2;
         p.direct = 0;
     } else {
+        // bounded path below 128 samples, or FFT::compress (fft.rs:366-388) which transforms the
+        // frame as it is: any length; 2^a 3^b lengths >= 128 still go through the Stockham stages
         p.L = n;
         p.pre = 0;
-        p.direct = 1;
+        p.direct = (n < 128 || !is_decomposable(n)) ? 1 : 0;
     }
     p.bins = p.L / 2 + 1;
     p.mf = (3 >= n / 100) ? 3 : n / 100;
@@ -257,7 +263,7 @@ extern "C" const char *atsc_strerror(int rc)
     case ATSC_E_INVALID: return "invalid argument";
     case ATSC_E_NOMEM: return "out of memory";
     case ATSC_E_UNSUPPORTED:
-        return "not implemented on the GPU path yet (frames > 4096 samples, unbounded fft)";
+        return "not implemented on the GPU path yet (frames longer than 4096 samples)";
     case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case ATSC_E_HIP: return "HIP runtime error";
     case ATSC_E_CAPACITY: return "output buffer too small";
@@ -339,7 +345,7 @@ extern "C" int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t 
 // ------------------------------------------------------------------------------------------
 // compress plan
 // ------------------------------------------------------------------------------------------
-static void free_trial(TrialPlan *t)
+static void free_sub(SubPlan *t)
 {
     if (!t) return;
     free_tables(t->tabs);
@@ -352,7 +358,8 @@ static void free_trial(TrialPlan *t)
 extern "C" void atsc_plan_destroy(atsc_plan *p)
 {
     if (!p) return;
-    for (int i = 0; i < 7; ++i) free_trial(p->trials[i]);
+    for (int i = 0; i < 7; ++i) free_sub(p->trials[i]);
+    free_sub(p->nopad);
     free_tables(p->tabs);
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_ids) (void)hipFree(p->d_ids);
@@ -478,43 +485,80 @@ extern "C" uint64_t atsc_plan_body_bound(const atsc_plan *p) { return p ? p->bod
 
 static const uint32_t COMPRESSION_SPEED[7] = {0x7fffffffu, 4096, 2048, 1024, 512, 256, 128};  // frame/mod.rs:22
 
-static int get_trial(atsc_ctx *ctx, const atsc_plan *plan, int level, TrialPlan **out)
+// Builds a SubPlan over the frames with n >= min_n; frame length override `force_n` (0 = keep).
+static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint32_t force_n, bool nopad,
+                     bool want_res, SubPlan **out)
 {
     *out = nullptr;
-    if (plan->trials[level]) { *out = plan->trials[level]; return ATSC_OK; }
-    const uint32_t S = COMPRESSION_SPEED[level];
-    TrialPlan *t = new (std::nothrow) TrialPlan();
+    SubPlan *t = new (std::nothrow) SubPlan();
     if (!t) return ATSC_E_NOMEM;
-    t->min_n = S;
+    t->min_n = min_n;
+    t->class_count.assign(N_CLASSES, 0);
+    t->class_lds.assign(N_CLASSES, 0);
+    t->class_first.assign(N_CLASSES, 0);
     std::vector<DevFrame> fr(plan->h_frames);
-    std::vector<uint32_t> ids;
-    for (size_t f = 0; f < fr.size(); ++f)
-        if (fr[f].n >= S) ids.push_back((uint32_t)f);
-    t->count = (uint32_t)ids.size();
+    std::vector<uint32_t> sel;
+    std::vector<int> cls;
+    std::map<uint32_t, uint64_t> tw_by_L;
+    for (size_t f = 0; f < fr.size(); ++f) {
+        if (fr[f].n < min_n) continue;
+        const uint32_t n = force_n ? force_n : fr[f].n;
+        auto it = t->tabs.by_n.find(n);
+        uint32_t pi;
+        if (it == t->tabs.by_n.end()) {
+            int rc = build_plan_entry(n, t->tabs, tw_by_L, nopad);
+            if (rc) { free_sub(t); return fail(ctx, rc, "sub plan entry"); }
+            pi = t->tabs.by_n[n];
+        } else {
+            pi = it->second;
+        }
+        const DevPlan &dp = t->tabs.plans[pi];
+        const int c = class_of(n, dp.L);
+        if (c < 0) { free_sub(t); return fail(ctx, ATSC_E_UNSUPPORTED, "sub plan: frame class"); }
+        fr[f].n = n;
+        fr[f].plan = pi;
+        sel.push_back((uint32_t)f);
+        cls.push_back(c);
+        t->class_count[c]++;
+        t->class_lds[c] = std::max(t->class_lds[c], dp.lds_bytes);
+    }
+    t->count = (uint32_t)sel.size();
     if (t->count) {
-        std::map<uint32_t, uint64_t> tw_by_L;
-        int rc = build_plan_entry(S, t->tabs, tw_by_L);
-        if (rc) { free_trial(t); return fail(ctx, rc, "trial plan entry"); }
-        const DevPlan &dp = t->tabs.plans[0];
-        t->cls = class_of(S, dp.L);
-        t->lds = dp.lds_bytes;
-        for (uint32_t id : ids) { fr[id].n = S; fr[id].plan = 0; }
-        rc = upload_tables(ctx, t->tabs);
-        if (rc) { free_trial(t); return rc; }
+        std::vector<uint32_t> ids(sel.size());
+        uint32_t acc = 0;
+        for (int c = 0; c < N_CLASSES; ++c) { t->class_first[c] = acc; acc += t->class_count[c]; }
+        std::vector<uint32_t> cur(t->class_first);
+        for (size_t i = 0; i < sel.size(); ++i) ids[cur[cls[i]]++] = sel[i];
+        int rc = upload_tables(ctx, t->tabs);
+        if (rc) { free_sub(t); return rc; }
 #define TCHK(call)                                                                      \
     do {                                                                                \
         hipError_t e__ = (call);                                                        \
-        if (e__ != hipSuccess) { free_trial(t); return fail(ctx, ATSC_E_HIP, #call, e__); } \
+        if (e__ != hipSuccess) { free_sub(t); return fail(ctx, ATSC_E_HIP, #call, e__); } \
     } while (0)
         TCHK(hipMalloc((void **)&t->d_frames, fr.size() * sizeof(DevFrame)));
         TCHK(hipMemcpy(t->d_frames, fr.data(), fr.size() * sizeof(DevFrame), hipMemcpyHostToDevice));
         TCHK(hipMalloc((void **)&t->d_ids, ids.size() * sizeof(uint32_t)));
         TCHK(hipMemcpy(t->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        TCHK(hipMalloc((void **)&t->d_res, fr.size() * sizeof(DevResult)));
+        if (want_res) TCHK(hipMalloc((void **)&t->d_res, fr.size() * sizeof(DevResult)));
 #undef TCHK
     }
-    plan->trials[level] = t;
     *out = t;
+    return ATSC_OK;
+}
+
+static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, const double *d_samples,
+                      const KParams &prm, DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+{
+    UniArgs nouni;
+    memset(&nouni, 0, sizeof(nouni));
+    for (int c = 0; c < N_CLASSES; ++c) {
+        if (!t->class_count[c]) continue;
+        hipError_t e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
+                                             t->d_ids + t->class_first[c], t->tabs.d_plans, t->tabs.d_tw,
+                                             prm, plan->d_slots, res, diag, nouni, s);
+        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress (sub plan)", e);
+    }
     return ATSC_OK;
 }
 
@@ -530,8 +574,6 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         if (!bounded) return fail(ctx, ATSC_E_INVALID, "compress: Auto needs the bounded path (compressor/mod.rs:72 todo!())");
         break;
     case ATSC_FFT:
-        if (!bounded) return fail(ctx, ATSC_E_UNSUPPORTED, "compress: unbounded fft");
-        break;
     case ATSC_POLYNOMIAL:
     case ATSC_IDW:
     case ATSC_NOOP:
@@ -581,21 +623,39 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     prm.trial_min_n = 0;
     prm.trial_res = nullptr;
     if (compressor == ATSC_AUTO && sample_level > 0) {
-        TrialPlan *t = nullptr;
-        int rc = get_trial(ctx, plan, sample_level, &t);
-        if (rc) return rc;
+        if (!plan->trials[sample_level]) {
+            SubPlan *t = nullptr;
+            const uint32_t S = COMPRESSION_SPEED[sample_level];
+            int rc = build_sub(ctx, plan, S, S, false, true, &t);
+            if (rc) return rc;
+            plan->trials[sample_level] = t;
+        }
+        const SubPlan *t = plan->trials[sample_level];
         if (t->count) {
             KParams tp = prm;
             tp.trial = 1;
-            UniArgs nouni;
-            memset(&nouni, 0, sizeof(nouni));
-            hipError_t e = launch_compress_class(t->cls, t->count, t->lds, d_samples, t->d_frames, t->d_ids,
-                                                 t->tabs.d_plans, t->tabs.d_tw, tp, plan->d_slots, t->d_res,
-                                                 nullptr, nouni, s);
-            if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress (trial)", e);
+            int rc = launch_sub(ctx, plan, t, d_samples, tp, t->d_res, nullptr, s);
+            if (rc) return rc;
             prm.trial_res = t->d_res;
             prm.trial_min_n = t->min_n;
         }
+    }
+    if (compressor == ATSC_FFT && !bounded) {
+        // Compressor::compress -> fft() (compressor/mod.rs:67, fft.rs:466-484): the frame is
+        // transformed unpadded at its own length
+        if (!plan->nopad) {
+            SubPlan *t = nullptr;
+            int rc = build_sub(ctx, plan, 0, 0, true, false, &t);
+            if (rc) return rc;
+            plan->nopad = t;
+        }
+        int rc = launch_sub(ctx, plan, plan->nopad, d_samples, prm, plan->d_res, d_diag, s);
+        if (rc) return rc;
+        hipError_t e = launch_pack(plan->d_frames, plan->d_res, plan->n_frames, plan->d_local,
+                                   plan->d_blocksum, plan->d_slots, d_body, body_cap, d_rec_off,
+                                   d_chosen, d_err, s);
+        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
+        return ATSC_OK;
     }
     int dominant = 0;
     for (int c = 1; c < N_CLASSES; ++c)

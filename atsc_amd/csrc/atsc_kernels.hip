@@ -399,7 +399,9 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             const uint32_t magicL = P.magicL;
             uint32_t used = 0, jump = 0, big = 0;
             double cur = prm.max_err + 1.0;
-            while (prm.max_err_m < sat_i32(cur * 1000.0)) {  // fft.rs:334
+            // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
+            // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
+            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
                 ++fft_trips;
                 const uint32_t K = min(P.mf + jump, Z);
                 for (; used < K; ++used) {
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                         }
                     }
                 }
+                if (!prm.bounded) { cur = 0.0; break; }
                 double s = 0.0;
 #pragma unroll
                 for (int m = 0; m < SPL; ++m) {

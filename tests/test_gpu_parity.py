@@ -370,3 +370,25 @@ def test_reference_kat_vectors_on_gpu(ctx, A):
     # data.rs:146-154 whole stream
     rec, _, _, _ = ctx.compress_host(np.ones(1024), [0, 1024], A.CONSTANT, False, 0.0, 0)
     assert A.bro_prefix(1) + rec == bytes(K.STREAM_CONSTANT_1024)
+
+
+def test_unbounded_fft(ctx, A, oracle):
+    """Compressor::compress(FFT) -> fft() (fft.rs:466-484, :366-388): no Gibbs padding, transform
+    length = frame length (2^a 3^b through the Stockham stages, anything else through the direct DFT),
+    the max(3, n/100) largest bins, no error loop."""
+    from tests.golden import kat as K
+
+    sizes = [12, 100, 127, 128, 256, 300, 1000, 1024, 2187, 4096, 4095, 3, 7]
+    xs, offs = [np.array(K.V12)], [0, 12]
+    for k, n in enumerate(sizes[1:]):
+        xs.append(H.synth_series(500 + k, n, klass=(0, 1, 2)[k % 3]))
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.FFT, False, 0.0)
+    _log(P.assert_summary(s, len(sizes), "unbounded FFT"))
+    # fft.rs:571-579: the decoded values of the 12-sample vector are pinned to 5 decimals
+    out = ctx.decompress_host(s["records"])
+    assert list(out[:12]) == K.FFT_LOSSY_OUT[1]
+    ref = oracle.decompress_data(A.bro_prefix(len(sizes)) + s["records"])
+    assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-5
