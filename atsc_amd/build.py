@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libatsc_hip.so")
-SOURCES = ["atsc_kernels.hip", "atsc_decode.hip", "atsc_host.cpp"]
+SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp"]
 DEPS = SOURCES + ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
 # -ffp-contract=off: the f64 spline / rounding arithmetic must evaluate exactly as written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]

@@ -21,6 +21,11 @@ hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const do
                                  const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                  const float2 *twpool, const KParams &prm, uint8_t *slots,
                                  DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s);
+hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
+                                 const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
+                                 const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
+                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s);
+uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
@@ -33,8 +38,11 @@ hipError_t launch_decompress(const struct DevDFrame *frames, uint64_t n_frames, 
 
 using namespace atsc;
 
-static const int N_CLASSES = 6;
-static const uint32_t MAX_FRAME_TIER_M = 4096;  // larger frames need the global-memory FFT tier
+static const int N_CLASSES = 7;       // 0..5: LDS-resident frame kernels, 6: large frames (atsc_large.hip)
+static const int CLASS_LARGE = 6;
+static const uint32_t MAX_FRAME_TIER_M = 4096;   // longest frame of the LDS-resident kernels
+static const uint32_t MAX_FRAME = 131072;        // MAX_FRAME_SIZE of the reference chunker (optimizer/mod.rs:27)
+static const uint32_t LARGE_WS_SLOTS = 256;      // large frames in flight (one workgroup + workspace each)
 
 struct atsc_ctx {
     int device = 0;
@@ -88,6 +96,9 @@ struct atsc_plan {
     uint8_t *d_slots = nullptr;
     uint32_t *d_local = nullptr;
     uint64_t *d_blocksum = nullptr;
+    unsigned char *d_ws = nullptr;   // workspace of the large-frame kernel
+    uint64_t ws_stride = 0;
+    uint32_t ws_slots = 0;
 };
 
 struct atsc_dplan {
@@ -146,7 +157,8 @@ extern "C" uint64_t atsc_payload_bound_bytes(uint64_t n)
 {
     // worst case over codecs: RLE with every value distinct  2 + varint(D) + n*(8 + 1 + varint(idx));
     // Noop 1 + varint(n) + 9n ; Polynomial store-all 2 + varint(n) + 8n + 17
-    return 32 + 14 * n;
+    // (run indices >= 65536 take 5 varint bytes)
+    return 32 + (n > 65535 ? 17 : 14) * n;
 }
 
 static int class_of(uint32_t n, uint32_t L)
@@ -157,6 +169,7 @@ static int class_of(uint32_t n, uint32_t L)
     if (L <= 1280) return 3;                              // <4,5>
     if (L <= 2304) return 4;                              // <4,9>
     if (L <= 5120 && n <= MAX_FRAME_TIER_M) return 5;     // <16,5>
+    if (n <= MAX_FRAME) return CLASS_LARGE;
     return -1;
 }
 
@@ -263,7 +276,7 @@ extern "C" const char *atsc_strerror(int rc)
     case ATSC_E_INVALID: return "invalid argument";
     case ATSC_E_NOMEM: return "out of memory";
     case ATSC_E_UNSUPPORTED:
-        return "not implemented on the GPU path yet (frames longer than 4096 samples)";
+        return "not implemented on the GPU path (idw or decode of frames longer than 4096 samples; frames longer than 131072)";
     case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case ATSC_E_HIP: return "HIP runtime error";
     case ATSC_E_CAPACITY: return "output buffer too small";
@@ -367,6 +380,7 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->d_local) (void)hipFree(p->d_local);
     if (p->d_blocksum) (void)hipFree(p->d_blocksum);
+    if (p->d_ws) (void)hipFree(p->d_ws);
     delete p;
 }
 
@@ -393,9 +407,9 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
             return fail(ctx, ATSC_E_INVALID, "plan_create: empty or unordered frame");
         }
         const uint64_t n64 = frame_off[f + 1] - frame_off[f];
-        if (n64 > MAX_FRAME_TIER_M) {
+        if (n64 > MAX_FRAME) {
             atsc_plan_destroy(p);
-            return fail(ctx, ATSC_E_UNSUPPORTED, "plan_create: frame longer than 4096 samples");
+            return fail(ctx, ATSC_E_UNSUPPORTED, "plan_create: frame longer than 131072 samples");
         }
         const uint32_t n = (uint32_t)n64;
         auto it = p->tabs.by_n.find(n);
@@ -413,6 +427,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
         cls[f] = c;
         p->class_count[c]++;
         p->class_lds[c] = std::max(p->class_lds[c], dp.lds_bytes);
+        if (c == CLASS_LARGE) p->ws_stride = std::max(p->ws_stride, large_ws_bytes(n, dp.L, dp.kcap));
         frames[f].sample_off = frame_off[f];
         frames[f].slot_off = slot;
         frames[f].n = n;
@@ -450,7 +465,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
                  f.sample_off == f0.sample_off + (uint64_t)i * f0.n &&
                  f.slot_off == f0.slot_off + (uint64_t)i * stride;
         }
-        if (ok && !getenv("ATSC_NO_UNIFORM")) {
+        if (ok && c != CLASS_LARGE && !getenv("ATSC_NO_UNIFORM")) {
             u.enabled = 1;
             u.fid0 = cid[0];
             u.sample_off0 = f0.sample_off;
@@ -475,6 +490,10 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
     PCHK(hipMalloc((void **)&p->d_slots, std::max<uint64_t>(slot, 16)));
     PCHK(hipMalloc((void **)&p->d_local, n_frames * sizeof(uint32_t)));
     PCHK(hipMalloc((void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
+    if (p->class_count[CLASS_LARGE]) {
+        p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
+        PCHK(hipMalloc((void **)&p->d_ws, p->ws_stride * p->ws_slots));
+    }
 #undef PCHK
     *out = p;
     return ATSC_OK;
@@ -554,9 +573,15 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
     memset(&nouni, 0, sizeof(nouni));
     for (int c = 0; c < N_CLASSES; ++c) {
         if (!t->class_count[c]) continue;
-        hipError_t e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
-                                             t->d_ids + t->class_first[c], t->tabs.d_plans, t->tabs.d_tw,
-                                             prm, plan->d_slots, res, diag, nouni, s);
+        hipError_t e;
+        if (c == CLASS_LARGE)
+            e = launch_compress_large(t->class_count[c], d_samples, t->d_frames, t->d_ids + t->class_first[c],
+                                      t->tabs.d_plans, t->tabs.d_tw, prm, plan->d_slots, res, diag,
+                                      plan->d_ws, plan->ws_stride, plan->ws_slots, s);
+        else
+            e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
+                                      t->d_ids + t->class_first[c], t->tabs.d_plans, t->tabs.d_tw,
+                                      prm, plan->d_slots, res, diag, nouni, s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress (sub plan)", e);
     }
     return ATSC_OK;
@@ -583,6 +608,8 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     default:
         return fail(ctx, ATSC_E_INVALID, "compress: unknown compressor id");
     }
+    if (compressor == ATSC_IDW && plan->class_count[CLASS_LARGE])
+        return fail(ctx, ATSC_E_UNSUPPORTED, "compress: idw on frames longer than 4096 samples");
     hipStream_t s = (hipStream_t)stream;
     KParams prm;
     prm.max_err = (double)max_error;  // frame/mod.rs:67,118: `max_error as f64`
@@ -672,10 +699,17 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].first, s));
         }
-        hipError_t e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
-                                             plan->d_frames, plan->d_ids + plan->class_first[c],
-                                             plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
-                                             plan->d_res, d_diag, plan->class_uni[c], s);
+        hipError_t e;
+        if (c == CLASS_LARGE)
+            e = launch_compress_large(plan->class_count[c], d_samples, plan->d_frames,
+                                      plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
+                                      plan->tabs.d_tw, prm, plan->d_slots, plan->d_res, d_diag, plan->d_ws,
+                                      plan->ws_stride, plan->ws_slots, s);
+        else
+            e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
+                                      plan->d_frames, plan->d_ids + plan->class_first[c],
+                                      plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
+                                      plan->d_res, d_diag, plan->class_uni[c], s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
         if (timed) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].second, s));

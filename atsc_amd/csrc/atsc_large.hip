@@ -1,0 +1,847 @@
+// atsc_large.hip -- frames of 4097 .. 131072 samples (the sizes OptimizerPlan::get_chunks_sizes emits
+// for long series, atsc/src/optimizer/mod.rs:78-98; transform lengths up to 139968 = 2^6 3^7).
+//
+// Same algorithms and reference semantics as k_compress (atsc_kernels.hip); what changes is where the
+// data lives and how the FFT error ladder reconstructs:
+//   * one workgroup of 16 wavefronts per frame; samples are read from the caller's buffer, everything
+//     else (FFT ping-pong buffers, admitted spectrum, spline tangents, RLE records) sits in a
+//     per-workgroup workspace in HBM (L2 resident: ~3 MB for a 131072-sample frame);
+//   * each ladder trip admits up to n/200 new bins, so the incremental direct sum of the small-frame
+//     kernel (O(new bins * L)) loses to one inverse FFT of the Hermitian spectrum per trip:
+//     real-output trick, one complex FFT of length L/2 (fft.rs:338-344);
+//   * bin admission order: radix-select of the kcap largest f32 norms, then one LDS sort of
+//     (norm, position) keys (fft.rs:231-257).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "atsc_device.h"
+
+namespace atsc {
+
+constexpr int LW = 16;          // wavefronts per workgroup
+constexpr int LT = 64 * LW;     // threads
+
+DEVI float2 cmulc(float2 v, float2 w)  // v * (w.x - i w.y)
+{
+    return make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+}
+DEVI float2 cmulp(float2 v, float2 w)  // v * (w.x + i w.y)
+{
+    return make_float2(v.x * w.x - v.y * w.y, v.y * w.x + v.x * w.y);
+}
+
+// Stockham stages over global buffers (same butterflies as fft_forward in atsc_kernels.hip).
+DEVI float2 *fft_forward_g(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw)
+{
+    const uint32_t M = P.M, sc = P.sc;
+    uint32_t ncur = M, st = 1;
+    for (uint32_t s = 0; s < P.nstages; ++s) {
+        const uint32_t r = P.radix[s];
+        const uint32_t m = ncur / r;
+        const uint32_t nb = M / r;
+        const uint32_t magic = P.stmagic[s];
+        const uint32_t sm = st * m;
+        for (uint32_t t = threadIdx.x; t < nb; t += LT) {
+            const uint32_t p = (st == 1) ? t : __umulhi(t, magic);
+            const uint32_t q = t - p * st;
+            const uint32_t ib = q + st * p;
+            const uint32_t ob = q + st * (r * p);
+            const uint32_t tb = p * st * sc;
+            if (r == 4) {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
+                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+                const float2 t3 = make_float2(d.y, -d.x);
+                Y[ob] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                Y[ob + st] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * tb]);
+                Y[ob + 3 * st] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * tb]);
+            } else if (r == 2) {
+                const float2 a0 = X[ib], a1 = X[ib + sm];
+                Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
+                Y[ob + st] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), tw[tb]);
+            } else {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm];
+                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                const float h = 0.8660254037844386f;
+                const float2 t3 = make_float2(h * d.y, -h * d.x);
+                Y[ob] = make_float2(a0.x + t1.x, a0.y + t1.y);
+                Y[ob + st] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = X; X = Y; Y = tmp;
+        ncur = m;
+        st *= r;
+    }
+    return X;
+}
+
+// workspace carve (bytes) -- the host uses the same function to size a slot
+__host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
+struct LargeWs {
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, bytes;
+};
+__host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
+{
+    LargeWs w;
+    uint64_t o = 0;
+    const uint64_t cplx = 8ull * (L + 8);
+    w.o_a = o; o += lw_align(cplx);                 // FFT ping
+    w.o_b = o; o += lw_align(cplx);                 // FFT pong
+    w.o_c = o; o += lw_align(cplx);                 // inverse-transform partner (keeps the spectrum intact)
+    w.o_x = o; o += lw_align(8ull * (L / 2 + 8));   // admitted spectrum Xsel[0..L/2] (zero elsewhere)
+    w.o_nb = o; o += lw_align(4ull * (L + 8));      // norm bits per bin
+    w.o_sel = o; o += lw_align(12ull * (kcap + 8)); // admitted bins in admission order
+    w.o_mm = o; o += lw_align(16ull * (n / 2 + 8)); // spline tangents per segment
+    w.o_aux = o; o += lw_align(4ull * ((n > 65536 ? n : 65536) + 8));  // scans; u16-position owners in the ladder
+    w.o_rec = o; o += lw_align(8ull * (n + 8));     // RLE run records (start << 32 | end)
+    w.o_hp = o; o += lw_align(4ull * (n + 8));
+    w.o_tab = o; o += lw_align(8ull * (n + 8));     // RLE hash table, 2n slots
+    w.o_rps = o; o += lw_align(4ull * (n + 8));
+    w.o_rph = o; o += lw_align(4ull * (n + 8));
+    w.bytes = o;
+    return w;
+}
+uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap) { return large_ws_layout(n, L, kcap).bytes; }
+
+// exclusive scan over a (global) u32 array by one workgroup; returns the total
+DEVI uint32_t lscan(uint32_t *arr, uint32_t count, uint32_t *wsum)
+{
+    return block_excl_scan<LW>(arr, count, wsum);
+}
+
+// sort of u64 run records rec = (start << 32 | end) by (bits of xs[end], start)
+DEVI void sort_runs_g(uint64_t *rec, const double *xs, uint32_t count, uint32_t P2)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t npairs = P2 >> 1;
+    auto ce = [&](uint32_t i, uint32_t l) {
+        if (l < count) {
+            const uint64_t ra = rec[i], rb = rec[l];
+            const uint64_t ka = (uint64_t)__double_as_longlong(xs[(uint32_t)ra]);
+            const uint64_t kb = (uint64_t)__double_as_longlong(xs[(uint32_t)rb]);
+            if (ka > kb || (ka == kb && ra > rb)) { rec[i] = rb; rec[l] = ra; }
+        }
+    };
+    uint32_t lk = 1;
+    for (uint32_t k = 2; k <= P2; k <<= 1, ++lk) {
+        const uint32_t half = k >> 1;
+        for (uint32_t t = tid; t < npairs; t += LT) {
+            const uint32_t i = ((t >> (lk - 1)) << lk) | (t & (half - 1));
+            ce(i, i ^ (k - 1));
+        }
+        __syncthreads();
+        for (uint32_t j = half >> 1; j >= 1; j >>= 1) {
+            for (uint32_t t = tid; t < npairs; t += LT) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                ce(i, i | j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_compress_large
+// --------------------------------------------------------------------------------------------
+constexpr uint32_t LKEYS_MAX = 16384;  // LDS sort capacity (kcap of a 131072-sample frame is 13100)
+
+__global__ __launch_bounds__(LT) void k_compress_large(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+    const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, unsigned char *__restrict__ ws_base,
+    uint64_t ws_stride)
+{
+    constexpr int T = LT;
+    constexpr int W = LW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t fid = ids[blockIdx.x];
+    const DevFrame fr = frames[fid];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins, M = P.M;
+
+    // LDS: [red 384][hist 256*4 + misc 64][keys 8*LKEYS_MAX | spline basis table]
+    double *red = (double *)smem;
+    uint32_t *wsum = (uint32_t *)(red + 32);
+    uint32_t *hist = (uint32_t *)(smem + 384);
+    uint32_t *bc = hist + 256;  // broadcast scalars
+    uint64_t *keys = (uint64_t *)(smem + 384 + 1024 + 64);
+    double4 *hbt = (double4 *)keys;
+    int parity = 0;
+
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    const LargeWs lay = large_ws_layout(n, L, P.kcap);
+    float2 *A = (float2 *)(ws + lay.o_a);
+    float2 *B = (float2 *)(ws + lay.o_b);
+    float2 *Cb = (float2 *)(ws + lay.o_c);
+    float2 *Xs = (float2 *)(ws + lay.o_x);
+    uint32_t *nbits = (uint32_t *)(ws + lay.o_nb);
+    Sel *sel = (Sel *)(ws + lay.o_sel);
+    double2 *mm = (double2 *)(ws + lay.o_mm);
+    uint32_t *aux = (uint32_t *)(ws + lay.o_aux);
+    uint64_t *rrec = (uint64_t *)(ws + lay.o_rec);
+    uint32_t *rhp = (uint32_t *)(ws + lay.o_hp);
+    uint32_t *tab = (uint32_t *)(ws + lay.o_tab);
+    uint32_t *rps = (uint32_t *)(ws + lay.o_rps);
+    uint32_t *rph = (uint32_t *)(ws + lay.o_rph);
+
+    const double *xs = samples + fr.sample_off;  // read in place (L2 keeps a 1 MB frame)
+    const float2 *tw = twpool + P.tw_off;
+    uint8_t *out = slots + fr.slot_off;
+    int mode = prm.mode;
+
+    auto gpad = [&](uint32_t j) -> double {  // fft.rs:184-204
+        int32_t i = (int32_t)j - (int32_t)pre;
+        i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
+        return xs[i];
+    };
+
+    // ---- stats --------------------------------------------------------------------------------
+    double smin, smax;
+    uint32_t bitdepth;
+    {
+        const double x0 = xs[0];
+        double mn = x0, mx = x0;
+        uint32_t fr_any = 0;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double v = xs[j];
+            fr_any |= frac_nonzero(v) ? 1u : 0u;
+            if (v > mx) mx = v;
+            if (v < mn) mn = v;
+        }
+        mn = block_minmax_f64<W, true>(mn, red, parity);
+        mx = block_minmax_f64<W, false>(mx, red, parity);
+        uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double v = xs[j];
+            if (v == mn) mni = min(mni, j);
+            if (v == mx) mxi = min(mxi, j);
+        }
+        mni = block_min_u32<W>(mni, red, parity);
+        mxi = block_min_u32<W>(mxi, red, parity);
+        fr_any = block_or_u32<W>(fr_any, red, parity);
+        smin = (mni < n) ? xs[mni] : x0;
+        smax = (mxi < n) ? xs[mxi] : x0;
+        int64_t maxi, mini;
+        bool fz;
+        split_n(smax, maxi, fz);
+        split_n(smin, mini, fz);
+        bitdepth = fr_any ? 0u : bitdepth_of(maxi, mini);
+    }
+
+    atsc_frame_diag dg;
+    dg.fft_size = dg.poly_size = dg.rle_size = 0xFFFFFFFFu;
+    dg.fft_trips = dg.fft_k = dg.poly_trips = dg.poly_step = 0;
+    dg.poly_points = 0;
+    dg.fft_err = dg.poly_err = 0.0;
+
+    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && !prm.trial && smin == smax)) {
+        if (tid == 0) {
+            out[0] = 30;
+            out[1] = (uint8_t)bitdepth;
+            const uint32_t vb = put_value(out + 2, bitdepth, smin);
+            res[fid].err = 0.0;
+            res[fid].len = 2 + vb;
+            res[fid].chosen = ATSC_CONSTANT;
+            if (diag) diag[fid] = dg;
+        }
+        return;
+    }
+    if (mode == ATSC_NOOP) {
+        for (uint32_t j = tid; j < n; j += T) aux[j] = vlen(zigzag(sat_i64(round(xs[j]))));
+        __syncthreads();
+        const uint32_t tot = lscan(aux, n, wsum);
+        const uint32_t hdr = 1 + vlen(n);
+        for (uint32_t j = tid; j < n; j += T)
+            put_varint(out + hdr + aux[j], zigzag(sat_i64(round(xs[j]))));
+        if (tid == 0) {
+            out[0] = 250;
+            put_varint(out + 1, n);
+            res[fid].err = 0.0;
+            res[fid].len = hdr + tot;
+            res[fid].chosen = ATSC_NOOP;
+            if (diag) diag[fid] = dg;
+        }
+        return;
+    }
+    if (mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
+        mode = (int)prm.trial_res[fid].chosen;
+
+    // =========================================================================================
+    // FFT candidate (fft.rs:288-362)
+    // =========================================================================================
+    const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
+    uint32_t fft_k = 0, fft_size = 0xFFFFFFFFu, fft_trips = 0;
+    double fft_err = 0.0;
+    const float mxf = (float)smax, mnf = (float)smin;
+    if (run_fft) {
+        if (mxf == mnf) {
+            fft_k = 0;
+            fft_size = 1 + 1 + 8;
+        } else {
+            // ---- forward transform of the padded f32 signal ----
+            float2 *spec;
+            if (P.half) {
+                float *Af = (float *)A;
+                for (uint32_t j = tid; j < L; j += T) Af[j] = (float)gpad(j);
+                __syncthreads();
+                float2 *Z = fft_forward_g(P, A, B, tw);
+                spec = (Z == A) ? B : A;
+                for (uint32_t k = tid; k <= M; k += T) {  // untangle (see fft_untangle)
+                    const float2 zk = Z[k == M ? 0 : k];
+                    const float2 zm = Z[k == 0 ? 0 : M - k];
+                    const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+                    const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);
+                    const float2 t = cmulc(make_float2(b.y, -b.x), tw[k]);
+                    spec[k] = make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+                }
+                __syncthreads();
+            } else {
+                for (uint32_t j = tid; j < L; j += T) A[j] = make_float2((float)gpad(j), 0.0f);
+                __syncthreads();
+                spec = fft_forward_g(P, A, B, tw);
+            }
+            float2 *work = (spec == A) ? B : A;  // free FFT buffer from here on
+
+            // ---- admission order: the kcap largest norms, descending, ties by position ----
+            uint32_t nz = 0;
+            for (uint32_t k = tid; k < bins; k += T) {
+                const float2 z = spec[k];
+                nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+                nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                Xs[k] = make_float2(0.0f, 0.0f);
+            }
+            __syncthreads();
+            const uint32_t Z = block_sum_u32<W>(nz, red, parity);
+            const uint32_t kcap = min(P.kcap, LKEYS_MAX);
+            uint32_t nkeys = 0;
+            if (bins <= kcap) {
+                for (uint32_t k = tid; k < bins; k += T)
+                    keys[k] = ((uint64_t)(~nbits[k]) << 32) | (uint64_t)k;
+                nkeys = bins;
+                __syncthreads();
+            } else {
+                // radix select of the kcap-th largest norm-bit pattern, 8 bits per pass
+                uint32_t prefix = 0, remaining = kcap;
+                for (int shift = 24; shift >= 0; shift -= 8) {
+                    for (uint32_t i = tid; i < 256; i += T) hist[i] = 0;
+                    __syncthreads();
+                    const uint32_t himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+                    for (uint32_t k = tid; k < bins; k += T) {
+                        const uint32_t v = nbits[k];
+                        if ((v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        uint32_t acc = 0, b = 255;
+                        for (;; --b) {
+                            if (acc + hist[b] >= remaining || b == 0) break;
+                            acc += hist[b];
+                        }
+                        bc[0] = b;
+                        bc[1] = remaining - acc;
+                    }
+                    __syncthreads();
+                    prefix |= bc[0] << shift;
+                    remaining = bc[1];
+                    __syncthreads();
+                }
+                const uint32_t thr = prefix;        // kcap-th largest value
+                const uint32_t need_ties = remaining;  // how many bins equal to thr are admitted
+                // bins above the threshold: any order (the sort fixes it)
+                if (tid == 0) bc[2] = 0;
+                __syncthreads();
+                for (uint32_t k = tid; k < bins; k += T) {
+                    const uint32_t v = nbits[k];
+                    if (v > thr) {
+                        const uint32_t slot = atomicAdd(&bc[2], 1u);
+                        keys[slot] = ((uint64_t)(~v) << 32) | (uint64_t)k;
+                    }
+                }
+                __syncthreads();
+                const uint32_t above = bc[2];
+                // ties: the first need_ties by ascending position (contiguous chunk per thread + scan)
+                const uint32_t C = (bins + T - 1) / T;
+                const uint32_t c0 = min(tid * C, bins), c1 = min(c0 + C, bins);
+                uint32_t cnt = 0;
+                for (uint32_t k = c0; k < c1; ++k) cnt += (nbits[k] == thr) ? 1u : 0u;
+                // exclusive scan of cnt over threads
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o);
+                    if ((tid & 63) >= (uint32_t)o) incl += t;
+                }
+                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t base = 0;
+                for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
+                uint32_t rank = base + incl - cnt;
+                __syncthreads();
+                for (uint32_t k = c0; k < c1; ++k) {
+                    if (nbits[k] == thr) {
+                        if (rank < need_ties) keys[above + rank] = ((uint64_t)(~thr) << 32) | (uint64_t)k;
+                        ++rank;
+                    }
+                }
+                nkeys = above + need_ties;
+                __syncthreads();
+            }
+            uint32_t p2 = 1;
+            while (p2 < nkeys) p2 <<= 1;
+            block_sort<W, true>(keys, nullptr, nkeys, p2);
+
+            // ---- ladder ----
+            const bool wraps = bins > 65536;
+            uint32_t *own = aux;
+            if (wraps) {
+                for (uint32_t i = tid; i < 65536; i += T) own[i] = 0;
+                __syncthreads();
+            }
+            const double mxd = (double)mxf, mnd = (double)mnf;
+            const double Ld = (double)L;
+            const float Lf = (float)L;
+            uint32_t used = 0, jump = 0;
+            double cur = prm.max_err + 1.0;
+            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
+                ++fft_trips;
+                const uint32_t K = min(min(P.mf + jump, Z), nkeys);
+                // admit bins used..K-1 (fft.rs:401-422: bins 0 and L/2 are purely real for the
+                // real output; an imaginary rounding residue there cannot reach idata[i].re)
+                // `pos as u16` (fft.rs:242): in a 131072-sample frame bins >= 65536 are stored -- and
+                // mirrored back by get_mirrored_freqs -- at pos - 65536, later entries overwriting
+                // earlier ones.  own[] keeps, per stored position, the latest admission index.
+                for (uint32_t i = used + tid; i < K; i += T) {
+                    const uint32_t pos = (uint32_t)(keys[i] & 0xffffffffu);
+                    const float2 z = spec[pos];
+                    sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
+                    if (wraps) atomicMax(&own[pos & 0xffffu], i + 1);
+                    else Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(z.x, 0.0f) : z;
+                }
+                __syncthreads();
+                if (wraps) {
+                    for (uint32_t i = used + tid; i < K; i += T) {
+                        const uint32_t p16 = sel[i].pos & 0xffffu;
+                        if (own[p16] == i + 1)
+                            Xs[p16] = (p16 == 0 || 2 * p16 == L) ? make_float2(sel[i].re, 0.0f)
+                                                                 : make_float2(sel[i].re, sel[i].im);
+                    }
+                    __syncthreads();
+                }
+                used = K;
+                if (!prm.bounded) { cur = 0.0; break; }
+                float2 *F;
+                if (P.half) {
+                    // Hermitian spectrum -> packed complex spectrum of (even + i odd) samples, conjugated
+                    // so that the forward butterflies deliver the inverse transform:
+                    //   E[k] = (X[k] + conj X[M-k]) / 2,  O[k] = (X[k] - conj X[M-k]) / 2 * conj(w^k),
+                    //   Zk = E + i O ;   idft_M(Zk) = conj(dft_M(conj Zk))
+                    for (uint32_t k = tid; k < M; k += T) {
+                        const float2 xk = Xs[k], xm = Xs[M - k];
+                        const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+                        const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+                        const float2 o = cmulp(d, tw[k]);
+                        // E + iO = (e.x - o.y) + i (e.y + o.x) ; store the conjugate
+                        work[k] = make_float2(e.x - o.y, -(e.y + o.x));
+                    }
+                    __syncthreads();
+                    F = fft_forward_g(P, work, Cb, tw);
+                } else {
+                    for (uint32_t k = tid; k < L; k += T) {
+                        float2 v = make_float2(0.0f, 0.0f);
+                        if (k <= L / 2) v = Xs[k];
+                        else { const float2 c = Xs[L - k]; v = make_float2(c.x, -c.y); }
+                        work[k] = make_float2(v.x, -v.y);  // conj for inverse-by-forward
+                    }
+                    __syncthreads();
+                    F = fft_forward_g(P, work, Cb, tw);
+                }
+                // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
+                double s = 0.0;
+                for (uint32_t j = tid; j < L; j += T) {
+                    float re;
+                    if (P.half) {
+                        const float2 f = F[j >> 1];
+                        re = 2.0f * ((j & 1) ? -f.y : f.x);  // idft_L = 2 * idft_M (even -> re, odd -> im)
+                    } else {
+                        re = F[j].x;
+                    }
+                    const double v = (double)(re / Lf);
+                    double o = div1e5(round(v * 100000.0));
+                    if (o > mxd) o = mxd;
+                    if (o < mnd) o = mnd;
+                    const double g = gpad(j);
+                    s += fabs((o - g) / g);
+                }
+                s = block_sum_f64<W>(s, red, parity);
+                cur = s / Ld;
+                if (fft_trips <= 17) jump += P.dk1;
+                else if (fft_trips <= 22) jump += P.dk2;
+                else break;
+            }
+            fft_err = cur;
+            fft_k = used;
+            uint32_t big = 0;
+            for (uint32_t i = tid; i < used; i += T) big += ((sel[i].pos & 0xffffu) >= 251) ? 1u : 0u;
+            big = block_sum_u32<W>(big, red, parity);
+            fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+            __syncthreads();
+        }
+        dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
+        dg.fft_err = fft_err;
+    }
+
+    // =========================================================================================
+    // Polynomial candidate (polynomial.rs:209-277); IDW is not offered for large frames
+    // =========================================================================================
+    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
+    uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
+    double poly_err = 0.0;
+    if (run_poly) {
+        if (smax == smin) {
+            poly_K = 0;
+            poly_step = 1;
+        } else if (!prm.bounded) {
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            poly_step = max(n / base, 1u);
+            const uint32_t cnt = (n + poly_step - 1) / poly_step;
+            poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
+        } else {
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+            double cur = prm.max_err + 1.0;
+            uint32_t jump = 0;
+            while (round(cur * 10000.0) > prm.poly_q_hi) {
+                ++poly_trips;
+                const uint32_t pts = base + jump;
+                const uint32_t step = max(n / pts, 1u);
+                const uint32_t cnt = (n + step - 1) / step;
+                const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                poly_step = step;
+                poly_K = K;
+                if (step > 1) {
+                    const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+                    const uint32_t gapL = (n - 1) - (K - 2) * step;
+                    const double stepd = (double)step, gapLd = (double)gapL;
+                    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                    __syncthreads();
+                    for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
+                        const uint32_t t0i = sg * step;
+                        const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                        const uint32_t tmi = (sg - 1) * step;
+                        const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                        const double t0 = (double)t0i, t1 = (double)t1i;
+                        const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+                        double2 t;
+                        t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                        t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                        mm[sg] = t;
+                    }
+                    for (uint32_t r = tid; r < step; r += T) {  // step <= 133: Hermite basis per offset
+                        const double nt = div_small((double)r, stepd, ry);
+                        const double t2 = nt * nt;
+                        const double t3 = t2 * nt;
+                        const double two_t3 = t3 * 2.0;
+                        const double two_t2 = t2 * 2.0;
+                        const double three_t2 = t2 * 3.0;
+                        double4 h;
+                        h.x = two_t3 - three_t2 + 1.0;
+                        h.y = t3 - two_t2 + nt;
+                        h.z = three_t2 - two_t3;
+                        h.w = t3 - t2;
+                        hbt[r] = h;
+                    }
+                    __syncthreads();
+                    double s = 0.0;
+                    for (uint32_t i = tid; i < n; i += T) {
+                        double sv;
+                        if (i == n - 1) {
+                            sv = xs[n - 1];
+                        } else {
+                            uint32_t sg = __umulhi(i, magic);
+                            if (sg > K - 2) sg = K - 2;
+                            const uint32_t t0i = sg * step;
+                            const bool last = (sg == K - 2);
+                            const uint32_t t1i = last ? (n - 1) : t0i + step;
+                            const double v0 = xs[t0i], v1 = xs[t1i];
+                            if (sg > 0 && !last) {
+                                const double2 t = mm[sg];
+                                const double4 h = hbt[i - t0i];
+                                sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
+                            } else {
+                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                            last ? ryL : ry);
+                                sv = v0 * (1.0 - nt) + v1 * nt;
+                            }
+                        }
+                        double o = div1e5(round(sv * 100000.0));
+                        if (o < smin) o = smin;
+                        else if (o > smax) o = smax;
+                        const double g = xs[i];
+                        s += fabs((o - g) / g);
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                }
+                if (poly_trips <= 17) jump += dj1;
+                else if (poly_trips <= 22) jump += dj2;
+                else if (round(cur * 10000.0) < prm.poly_q_lo) break;
+                else { poly_step = 1; poly_K = n; cur = 0.0; break; }
+                if (K == n) { cur = 0.0; break; }
+            }
+            poly_err = cur;
+        }
+        uint32_t vb = 0;
+        if (bitdepth == 0 || bitdepth == 3) {
+            vb = poly_K * (bitdepth == 0 ? 8u : 1u);
+        } else {
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                vb += value_bytes(bitdepth, xs[t]);
+            }
+            vb = block_sum_u32<W>(vb, red, parity);
+        }
+        poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
+        dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
+        dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
+    }
+
+    // =========================================================================================
+    // RLE candidate (rle.rs:142-189)
+    // =========================================================================================
+    const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
+    uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0;
+    bool rle_sorted = false;
+    auto run_key = [&](uint64_t rec) { return (uint64_t)__double_as_longlong(xs[(uint32_t)rec]); };
+    auto rle_sort_and_group = [&]() {
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += T)
+            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t R = lscan(aux, n, wsum);
+        uint32_t *ends = rhp;
+        for (uint32_t j = tid; j < n; j += T)
+            if (j + 1 >= n || xs[j + 1] != xs[j]) ends[aux[j]] = j;
+        __syncthreads();
+        for (uint32_t r = tid; r < R; r += T) {
+            const uint32_t st = r ? ends[r - 1] + 1 : 0;
+            rrec[r] = ((uint64_t)st << 32) | ends[r];
+        }
+        __syncthreads();
+        uint32_t p2 = 1;
+        while (p2 < R) p2 <<= 1;
+        sort_runs_g(rrec, xs, R, p2);
+        for (uint32_t i = tid; i < R; i += T)
+            aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t D = lscan(aux, R, wsum);
+        for (uint32_t i = tid; i < R; i += T)
+            if (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) rhp[aux[i]] = i;
+        if (tid == 0) rhp[D] = R;
+        __syncthreads();
+        uint32_t hb = 0;
+        for (uint32_t gi = tid; gi < D; gi += T) {
+            const uint32_t h0 = rhp[gi], h1 = rhp[gi + 1];
+            const uint32_t b = value_bytes(bitdepth, xs[(uint32_t)rrec[h0]]) + vlen(h1 - h0);
+            rph[gi] = b;
+            hb += b;
+        }
+        __syncthreads();
+        hb = block_sum_u32<W>(hb, red, parity);
+        rle_R = R;
+        rle_D = D;
+        rle_size = 2 + vlen(D) + hb + rle_ib;
+        rle_sorted = true;
+    };
+    if (run_rle) {
+        const double me = prm.max_err;
+        const bool pf = run_fft && (fft_err <= me), pp = run_poly && (poly_err <= me);
+        uint32_t best_other = 0xFFFFFFFFu;
+        if (pf) best_other = fft_size;
+        if (pp && poly_size < best_other) best_other = poly_size;
+        uint32_t rcnt = 0, ibs = 0;
+        for (uint32_t j = tid; j < n; j += T)
+            if (j == 0 || xs[j] != xs[j - 1]) { ++rcnt; ibs += vlen(j); }
+        const uint32_t R = block_sum_u32<W>(rcnt, red, parity);
+        const uint32_t ib = block_sum_u32<W>(ibs, red, parity);
+        rle_R = R;
+        rle_ib = ib;
+        const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
+        const uint32_t lb = 3 + ib + (R >= 2 ? 2u : 1u) * (minval + 1);
+        if (mode == ATSC_RLE || lb < best_other) {
+            if (R <= 1024 || mode == ATSC_RLE) {
+                rle_sort_and_group();
+            } else {
+                const uint32_t H = 2 * n;
+                __syncthreads();
+                for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
+                for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
+                __syncthreads();
+                uint32_t dnew = 0;
+                for (uint32_t j = tid; j < n; j += T) {
+                    if (j + 1 >= n || xs[j + 1] != xs[j]) {
+                        const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
+                        uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
+                            if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
+                            if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
+                            h = (h + 1 == H) ? 0 : h + 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t hb = 0;
+                for (uint32_t j = tid; j < n; j += T)
+                    if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
+                rle_D = block_sum_u32<W>(dnew, red, parity);
+                hb = block_sum_u32<W>(hb, red, parity);
+                rle_size = 2 + vlen(rle_D) + hb + ib;
+            }
+        } else {
+            rle_size = lb;
+        }
+        dg.rle_size = (mode == ATSC_RLE || lb < best_other) ? rle_size : 0xFFFFFFFEu;
+    }
+
+    // ---- selection (frame/mod.rs:113-147) ----
+    int chosen;
+    double chosen_err;
+    if (mode == ATSC_AUTO) {
+        const double me = prm.max_err;
+        const bool pf = fft_err <= me, pp = poly_err <= me;
+        chosen = ATSC_RLE;
+        uint32_t bs = rle_size;
+        if (pp && poly_size <= bs) { chosen = ATSC_POLYNOMIAL; bs = poly_size; }
+        if (pf && fft_size <= bs) { chosen = ATSC_FFT; bs = fft_size; }
+        chosen_err = chosen == ATSC_FFT ? fft_err : chosen == ATSC_POLYNOMIAL ? poly_err : 0.0;
+    } else {
+        chosen = mode;
+        chosen_err = mode == ATSC_FFT ? fft_err : mode == ATSC_POLYNOMIAL ? poly_err : 0.0;
+    }
+
+    uint32_t out_len = 0;
+    if (prm.trial) {
+        if (tid == 0) {
+            res[fid].err = chosen_err;
+            res[fid].len = 0;
+            res[fid].chosen = (uint32_t)chosen;
+        }
+        return;
+    }
+    if (chosen == ATSC_FFT) {
+        const uint32_t hdr = 1 + vlen(fft_k);
+        for (uint32_t i = tid; i < fft_k; i += T) aux[i] = vlen(sel[i].pos & 0xffffu) + 8;
+        __syncthreads();
+        const uint32_t body = lscan(aux, fft_k, wsum);
+        for (uint32_t i = tid; i < fft_k; i += T) {
+            uint8_t *p = out + hdr + aux[i];
+            p += put_varint(p, sel[i].pos & 0xffffu);
+            put_f32(p, sel[i].re);
+            put_f32(p + 4, sel[i].im);
+        }
+        if (tid == 0) {
+            out[0] = 15;
+            put_varint(out + 1, fft_k);
+            put_f32(out + hdr + body, mxf);
+            put_f32(out + hdr + body + 4, mnf);
+        }
+        out_len = hdr + body + 8;
+    } else if (chosen == ATSC_POLYNOMIAL) {
+        const uint32_t hdr = 2 + vlen(poly_K);
+        uint32_t body;
+        if (bitdepth == 0 || bitdepth == 3) {
+            const uint32_t vbytes = bitdepth == 0 ? 8u : 1u;
+            body = poly_K * vbytes;
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                put_value(out + hdr + k * vbytes, bitdepth, xs[t]);
+            }
+        } else {
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                aux[k] = value_bytes(bitdepth, xs[t]);
+            }
+            __syncthreads();
+            body = lscan(aux, poly_K, wsum);
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                put_value(out + hdr + aux[k], bitdepth, xs[t]);
+            }
+        }
+        if (tid == 0) {
+            out[0] = 0;
+            out[1] = (uint8_t)bitdepth;
+            put_varint(out + 2, poly_K);
+            put_f64(out + hdr + body, smin);
+            put_f64(out + hdr + body + 8, smax);
+            out[hdr + body + 16] = (uint8_t)poly_step;
+        }
+        out_len = hdr + body + 17;
+    } else {
+        if (!rle_sorted) rle_sort_and_group();
+        const uint32_t R = rle_R, D = rle_D;
+        const uint32_t hdr = 2 + vlen(D);
+        for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rrec[i] >> 32);
+        __syncthreads();
+        lscan(rps, R, wsum);
+        const uint32_t hb = lscan(rph, D, wsum);
+        uint32_t ibt = 0;
+        for (uint32_t i = tid; i < R; i += T) {
+            const uint64_t rec = rrec[i];
+            const uint32_t st = (uint32_t)(rec >> 32);
+            const bool head = (i == 0 || run_key(rec) != run_key(rrec[i - 1]));
+            const uint32_t gi = head ? aux[i] : aux[i] - 1;
+            const uint32_t ghb = (gi + 1 < D ? rph[gi + 1] : hb);
+            if (head) {
+                uint8_t *p = out + hdr + rph[gi] + rps[i];
+                p += put_value(p, bitdepth, xs[(uint32_t)rec]);
+                put_varint(p, rhp[gi + 1] - rhp[gi]);
+            }
+            put_varint(out + hdr + ghb + rps[i], st);
+            if (i == R - 1) ibt = rps[i] + vlen(st);
+        }
+        ibt = block_sum_u32<W>(ibt, red, parity);
+        if (tid == 0) {
+            out[0] = 60;
+            out[1] = (uint8_t)bitdepth;
+            put_varint(out + 2, D);
+        }
+        out_len = hdr + hb + ibt;
+    }
+    if (tid == 0) {
+        res[fid].err = chosen_err;
+        res[fid].len = out_len;
+        res[fid].chosen = (uint32_t)chosen;
+        if (diag) diag[fid] = dg;
+    }
+}
+
+hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
+                                 const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
+                                 const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
+                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s)
+{
+    const uint32_t lds = 384 + 1024 + 64 + 8 * LKEYS_MAX;
+    hipError_t e = hipFuncSetAttribute((const void *)k_compress_large,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
+        const uint32_t nb = min(ws_slots, count - b0);
+        hipLaunchKernelGGL(k_compress_large, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+                           twpool, prm, slots, res, diag, ws, ws_stride);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace atsc

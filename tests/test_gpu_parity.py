@@ -392,3 +392,35 @@ def test_unbounded_fft(ctx, A, oracle):
     assert list(out[:12]) == K.FFT_LOSSY_OUT[1]
     ref = oracle.decompress_data(A.bro_prefix(len(sizes)) + s["records"])
     assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# large frames: what the reference chunker emits for long series (optimizer/mod.rs:78-98)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sizes,klasses", [
+    ([8192, 5000, 6500, 16384, 4097], (0, 2, 3, 1)),   # 6500 -> L = 6561 = 3^8 (odd: full complex FFT)
+    ([32768, 65536], (0, 3)),
+    ([131072], (0,)),
+    ([131072], (1,)),                                    # busy signal: bins >= 65536 are admitted (u16 wrap)
+])
+def test_auto_large_frames(ctx, A, oracle, sizes, klasses):
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in klasses:
+            xs.append(H.synth_series(700 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, ME5)
+    _log(P.assert_summary(s, len(offs) - 1, "large frames %s classes %s codecs %s" % (sizes, klasses, s["codecs"])))
+
+
+def test_reference_chunker_long_series(ctx, A, oracle):
+    """compress_data flow (main.rs:130-165) on a 300000-sample series: 131072, 131072, 32768,
+    4096, 512, 480 -- every kernel tier in one batch, byte-compared at the stream level."""
+    x = H.synth_series(42, 300000, block=50000)
+    x = A.clean_data(x)
+    sizes = A.chunk_sizes(len(x))
+    assert sizes == [131072, 131072, 32768, 4096, 512, 480]
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME5)
+    _log(P.assert_summary(s, len(sizes), "chunker long series codecs %s" % s["codecs"]))
