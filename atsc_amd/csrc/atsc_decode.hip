@@ -14,45 +14,6 @@
 
 namespace atsc {
 
-struct Rd {
-    const uint8_t *p;
-    uint32_t len, pos;
-    bool bad;
-};
-DEVI uint32_t rd_u8(Rd &r)
-{
-    if (r.pos + 1 > r.len) { r.bad = true; return 0; }
-    return r.p[r.pos++];
-}
-DEVI uint64_t rd_le(Rd &r, uint32_t nb)
-{
-    if (r.pos + nb > r.len) { r.bad = true; return 0; }
-    uint64_t v = 0;
-    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)r.p[r.pos + i] << (8 * i);
-    r.pos += nb;
-    return v;
-}
-DEVI uint64_t rd_varint(Rd &r)
-{
-    const uint32_t t = rd_u8(r);
-    if (t < 251) return t;
-    if (t == 251) return rd_le(r, 2);
-    if (t == 252) return rd_le(r, 4);
-    if (t == 253) return rd_le(r, 8);
-    r.bad = true;
-    return 0;
-}
-DEVI int64_t unzig(uint64_t u) { return (u & 1) ? (int64_t)~(u >> 1) : (int64_t)(u >> 1); }
-// value at a bitdepth: constant.rs:71-92, polynomial.rs:95-116, rle.rs:76-100
-DEVI double rd_value(Rd &r, uint32_t bd)
-{
-    if (bd == 3) return (double)rd_u8(r);
-    if (bd == 2) return (double)(int16_t)unzig(rd_varint(r));
-    if (bd == 1) return (double)(int32_t)unzig(rd_varint(r));
-    return __longlong_as_double((long long)rd_le(r, 8));
-}
-DEVI float rd_f32(Rd &r) { return __uint_as_float((uint32_t)rd_le(r, 4)); }
-
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_decompress(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,

@@ -26,6 +26,10 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
                                  unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s);
 uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
+hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
+                                   const DevPlan *plans, const float2 *twpool, const uint8_t *body,
+                                   double *out, int *status, unsigned char *ws, uint64_t ws_stride,
+                                   uint32_t ws_slots, hipStream_t s);
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
@@ -109,6 +113,9 @@ struct atsc_dplan {
     DevDFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
     int *d_status = nullptr;
+    unsigned char *d_ws = nullptr;
+    uint64_t ws_stride = 0;
+    uint32_t ws_slots = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -865,6 +872,7 @@ extern "C" void atsc_dplan_destroy(atsc_dplan *p)
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_ids) (void)hipFree(p->d_ids);
     if (p->d_status) (void)hipFree(p->d_status);
+    if (p->d_ws) (void)hipFree(p->d_ws);
     delete p;
 }
 extern "C" uint64_t atsc_dplan_n_frames(const atsc_dplan *p) { return p ? p->n_frames : 0; }
@@ -905,9 +913,13 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
             if (dl < 2 || !host_get_varint(body, pos + dl, q, cnt)) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: noop payload"); }
             nout = cnt;
         }
-        if (nout == 0 || nout > MAX_FRAME_TIER_M) {
+        if (nout == 0 || nout > MAX_FRAME) {
             atsc_dplan_destroy(p);
             return fail(ctx, nout == 0 ? ATSC_E_FORMAT : ATSC_E_UNSUPPORTED, "dplan_create: frame sample count");
+        }
+        if (tag == ATSC_IDW && nout > MAX_FRAME_TIER_M) {
+            atsc_dplan_destroy(p);
+            return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: idw frame longer than 4096 samples");
         }
         const uint32_t n = (uint32_t)nout;
         auto it = p->tabs.by_n.find(n);
@@ -933,6 +945,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         cls.push_back(c);
         p->class_count[c]++;
         p->class_lds[c] = std::max(p->class_lds[c], dp.lds_bytes);
+        if (c == CLASS_LARGE) p->ws_stride = std::max(p->ws_stride, large_ws_bytes(n, dp.L, dp.kcap));
         out_off += n;
         pos += dl;
     }
@@ -959,6 +972,10 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
     PCHK(hipMemcpy(p->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     PCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
     PCHK(hipMemset(p->d_status, 0, sizeof(int)));
+    if (p->class_count[CLASS_LARGE]) {
+        p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
+        PCHK(hipMalloc((void **)&p->d_ws, p->ws_stride * p->ws_slots));
+    }
 #undef PCHK
     *out = p;
     return ATSC_OK;
@@ -971,9 +988,15 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
     hipStream_t s = (hipStream_t)stream;
     for (int c = 0; c < N_CLASSES; ++c) {
         if (!dp->class_count[c]) continue;
-        hipError_t e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
-                                         dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,
-                                         dp->tabs.d_tw, d_body, d_out, dp->d_status, s);
+        hipError_t e;
+        if (c == CLASS_LARGE)
+            e = launch_decompress_large(dp->class_count[c], dp->d_frames, dp->d_ids + dp->class_first[c],
+                                        dp->tabs.d_plans, dp->tabs.d_tw, d_body, d_out, dp->d_status,
+                                        dp->d_ws, dp->ws_stride, dp->ws_slots, s);
+        else
+            e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
+                                  dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,
+                                  dp->tabs.d_tw, d_body, d_out, dp->d_status, s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_decompress", e);
     }
     return ATSC_OK;

@@ -844,4 +844,257 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     return hipSuccess;
 }
 
+
+// --------------------------------------------------------------------------------------------
+// k_decompress_large: CompressorFrame::decompress for frames of 4097 .. 131072 samples
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LT) void k_decompress_large(
+    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
+    const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    constexpr int T = LT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const DevDFrame fr = frames[ids[blockIdx.x]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = fr.n, L = P.L, M = P.M, pre = P.pre;
+    double *out = outp + fr.out_off;
+    const uint8_t *pay = body + fr.payload_off;
+
+    struct Hdr {
+        double d0, d1;
+        uint32_t u0, u1, u2, bad;
+        float f0, f1;
+    };
+    Hdr *hdr = (Hdr *)smem;
+    uint32_t *wsum = (uint32_t *)(smem + 64);
+
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    const LargeWs lay = large_ws_layout(n, L, P.kcap);
+    float2 *A = (float2 *)(ws + lay.o_a);
+    float2 *Cb = (float2 *)(ws + lay.o_c);
+    float2 *Xs = (float2 *)(ws + lay.o_x);
+    double *vals = (double *)(ws + lay.o_tab);    // knot values / RLE group values (8n bytes)
+    uint64_t *keys = (uint64_t *)(ws + lay.o_rec);  // RLE (start << 32 | group)
+    const float2 *tw = twpool + P.tw_off;
+    (void)wsum;
+
+    // fixed-width point arrays (U8 / F64) are read in parallel after the header; the spectrum must be
+    // empty before lane 0 starts filling it
+    if (fr.tag == ATSC_FFT) {
+        for (uint32_t k = tid; k <= L / 2; k += T) Xs[k] = make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        Rd r{pay, fr.payload_len, 0, false};
+        Hdr h;
+        h.d0 = h.d1 = 0.0; h.u0 = h.u1 = h.u2 = 0; h.f0 = h.f1 = 0.0f;
+        switch (fr.tag) {
+        case ATSC_CONSTANT: {
+            (void)rd_u8(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            if (bd > 3) r.bad = true;
+            else h.d0 = rd_value(r, bd);
+            break;
+        }
+        case ATSC_NOOP: {
+            (void)rd_u8(r);
+            const uint64_t cnt = rd_varint(r);
+            if (cnt != n) r.bad = true;
+            for (uint32_t i = 0; i < n && !r.bad; ++i) out[i] = (double)unzig(rd_varint(r));
+            break;
+        }
+        case ATSC_IDW:
+        case ATSC_POLYNOMIAL: {
+            const uint32_t id = (uint32_t)rd_varint(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            const uint64_t cnt = rd_varint(r);
+            if (id != 0 || bd > 3 || cnt > n) r.bad = true;  // idw is not offered for large frames
+            h.u2 = bd;
+            h.u0 = (uint32_t)cnt;
+            if (!r.bad) {
+                if (bd == 0 || bd == 3) {
+                    h.u1 = r.pos;  // fixed-width points start here; read in parallel below
+                    r.pos += (uint32_t)cnt * (bd == 0 ? 8u : 1u);
+                    if (r.pos > r.len) r.bad = true;
+                } else {
+                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) vals[i] = rd_value(r, bd);
+                }
+            }
+            h.d0 = __longlong_as_double((long long)rd_le(r, 8));
+            h.d1 = __longlong_as_double((long long)rd_le(r, 8));
+            h.f0 = (float)rd_u8(r);  // point_step
+            break;
+        }
+        case ATSC_FFT: {
+            (void)rd_u8(r);
+            const uint64_t cnt = rd_varint(r);
+            if (cnt > L) r.bad = true;
+            // get_mirrored_freqs (fft.rs:401-422): entries are applied in stream order, later ones
+            // overwrite; a position above L/2 is the mirror of L - pos
+            for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
+                uint32_t pos = (uint32_t)rd_varint(r) & 0xffffu;
+                float re = rd_f32(r), im = rd_f32(r);
+                if (pos >= L) { r.bad = true; break; }
+                if (pos > L / 2) { pos = L - pos; im = -im; }
+                Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(re, 0.0f) : make_float2(re, im);
+            }
+            h.u0 = (uint32_t)cnt;
+            h.f0 = rd_f32(r);
+            h.f1 = rd_f32(r);
+            break;
+        }
+        case ATSC_RLE: {
+            (void)rd_u8(r);
+            const uint32_t bd = (uint32_t)rd_varint(r);
+            const uint64_t groups = rd_varint(r);
+            if (bd > 3 || groups > n) r.bad = true;
+            uint32_t e = 0;
+            for (uint32_t gi = 0; gi < groups && !r.bad; ++gi) {
+                vals[gi] = rd_value(r, bd);
+                const uint64_t cnt = rd_varint(r);
+                if (cnt > n - e) { r.bad = true; break; }
+                for (uint32_t k = 0; k < cnt && !r.bad; ++k) {
+                    const uint64_t idx = rd_varint(r);
+                    if (idx >= n) { r.bad = true; break; }
+                    keys[e++] = (idx << 32) | gi;
+                }
+            }
+            h.u0 = e;
+            break;
+        }
+        default: r.bad = true;
+        }
+        h.bad = r.bad ? 1u : 0u;
+        *hdr = h;
+        if (r.bad) atomicExch(status, 1);
+    }
+    __syncthreads();
+    const Hdr h = *hdr;
+    if (h.bad) return;
+
+    if (fr.tag == ATSC_CONSTANT) {
+        for (uint32_t j = tid; j < n; j += T) out[j] = h.d0;
+        return;
+    }
+    if (fr.tag == ATSC_NOOP) return;
+    if (fr.tag == ATSC_POLYNOMIAL || fr.tag == ATSC_IDW) {
+        const double mn = h.d0, mx = h.d1;
+        if (mx == mn) {
+            for (uint32_t j = tid; j < n; j += T) out[j] = mx;
+            return;
+        }
+        const uint32_t step = (uint32_t)h.f0, K = h.u0, bd = h.u2;
+        bool ok = step >= 1;
+        if (ok) {
+            const uint32_t cnt = (n + step - 1) / step;
+            const uint32_t Kp = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+            ok = (Kp == K) && K >= 2;
+        }
+        if (!ok) {
+            if (tid == 0) atomicExch(status, 1);
+            return;
+        }
+        if (bd == 0 || bd == 3) {
+            const uint8_t *pp = pay + h.u1;
+            for (uint32_t k = tid; k < K; k += T) {
+                if (bd == 3) {
+                    vals[k] = (double)pp[k];
+                } else {
+                    uint64_t v = 0;
+                    for (int b = 0; b < 8; ++b) v |= (uint64_t)pp[8 * k + b] << (8 * b);
+                    vals[k] = __longlong_as_double((long long)v);
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+        for (uint32_t j = tid; j < n; j += T) {
+            const double sv = spline_eval([&](uint32_t k) { return vals[k]; }, j, n, step, K, magic);
+            double o = round(sv * 100000.0) / 100000.0;
+            if (o < mn) o = mn;
+            else if (o > mx) o = mx;
+            out[j] = o;
+        }
+        return;
+    }
+    if (fr.tag == ATSC_FFT) {
+        const float mxf = h.f0, mnf = h.f1;
+        if (mxf == mnf) {
+            for (uint32_t j = tid; j < n; j += T) out[j] = (double)mxf;
+            return;
+        }
+        float2 *F;
+        if (P.half) {
+            for (uint32_t k = tid; k < M; k += T) {
+                const float2 xk = Xs[k], xm = Xs[M - k];
+                const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+                const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+                const float2 o = cmulp(d, tw[k]);
+                A[k] = make_float2(e.x - o.y, -(e.y + o.x));
+            }
+        } else {
+            for (uint32_t k = tid; k < L; k += T) {
+                float2 v;
+                if (k <= L / 2) v = Xs[k];
+                else { const float2 c = Xs[L - k]; v = make_float2(c.x, -c.y); }
+                A[k] = make_float2(v.x, -v.y);
+            }
+        }
+        __syncthreads();
+        F = fft_forward_g(P, A, Cb, tw);
+        const double mxd = (double)mxf, mnd = (double)mnf;
+        const float Lf = (float)L;
+        for (uint32_t i = tid; i < n; i += T) {
+            const uint32_t j = i + pre;
+            float re;
+            if (P.half) {
+                const float2 f = F[j >> 1];
+                re = 2.0f * ((j & 1) ? -f.y : f.x);
+            } else {
+                re = F[j].x;
+            }
+            const float v = re / Lf;
+            double o = round((double)v * 100000.0) / 100000.0;
+            if (o > mxd) o = mxd;
+            if (o < mnd) o = mnd;
+            out[i] = o;
+        }
+        return;
+    }
+    {  // RLE (rle.rs:204-236)
+        const uint32_t E = h.u0;
+        uint32_t p2 = 1;
+        while (p2 < E) p2 <<= 1;
+        block_sort<LW, true>(keys, nullptr, E, p2);
+        for (uint32_t j = tid; j < n; j += T) {
+            uint32_t lo = 0, hi = E;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)(keys[mid] >> 32) <= j) lo = mid + 1;
+                else hi = mid;
+            }
+            out[j] = lo ? vals[(uint32_t)(keys[lo - 1] & 0xffffffffu)] : 0.0;
+        }
+    }
+}
+
+hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, const uint32_t *ids,
+                                   const DevPlan *plans, const float2 *twpool, const uint8_t *body,
+                                   double *out, int *status, unsigned char *ws, uint64_t ws_stride,
+                                   uint32_t ws_slots, hipStream_t s)
+{
+    for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
+        const uint32_t nb = min(ws_slots, count - b0);
+        hipLaunchKernelGGL(k_decompress_large, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
+                           body, out, status, ws, ws_stride);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace atsc

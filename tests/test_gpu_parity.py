@@ -424,3 +424,46 @@ def test_reference_chunker_long_series(ctx, A, oracle):
     off = np.cumsum([0] + sizes).astype(np.uint64)
     s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME5)
     _log(P.assert_summary(s, len(sizes), "chunker long series codecs %s" % s["codecs"]))
+
+
+def test_decompress_large_frames(ctx, A, oracle):
+    """Decode the ORACLE's stream of large frames on the GPU and compare with the oracle's decode."""
+    sizes = [8192, 6500, 16384, 131072]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in ((0, 1, 2, 3) if n < 100000 else (0, 1)):
+            xs.append(H.synth_series(800 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    nf = len(off) - 1
+    for comp, bounded in ((A.AUTO, True), (A.FFT, True), (A.POLYNOMIAL, True), (A.RLE, False),
+                          (A.NOOP, False), (A.CONSTANT, False)):
+        bro, chosen, _ = oracle.stream_compress(x, off, comp, bounded, ME5, 0)
+        ref = oracle.decompress_data(bro)
+        body_off, nfr = A.bro_open(bro)
+        out = ctx.decompress_host(bro[body_off:])
+        assert len(out) == len(ref)
+        for i in range(nf):
+            seg = slice(int(off[i]), int(off[i + 1]))
+            if chosen[i] == oracle.FFT:
+                n = int(off[i + 1] - off[i])
+                scale = max(np.max(np.abs(ref[seg])), 1e-30)
+                tol = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5  # f32 FFT of length ~n
+                assert np.max(np.abs(out[seg] - ref[seg])) <= tol, (comp, i, np.max(np.abs(out[seg] - ref[seg])), tol)
+            else:
+                assert np.array_equal(out[seg], ref[seg]), (comp, i, chosen[i])
+
+
+def test_roundtrip_long_series_e2e(ctx, A, oracle):
+    """compress_data / decompress_data (main.rs:130-172) on a long series: GPU stream decoded by the
+    GPU and by the oracle; MAPE bound as e2e.rs:234-248."""
+    x = H.synth_series(43, 200000, klass=0)
+    sizes = A.chunk_sizes(len(x))
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    rec, _, chosen, err = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+    out = ctx.decompress_host(rec)
+    ref = oracle.decompress_data(A.bro_prefix(len(sizes)) + rec)
+    assert len(out) == len(x) == len(ref)
+    assert H.mape(x, out) <= ME5 and H.mape(x, ref) <= ME5
+    assert np.max(np.abs(out - ref)) <= 30 * 1300 * 2.0 ** -23
