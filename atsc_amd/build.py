@@ -6,7 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libatsc_hip.so")
-SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp"]
+SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp", "atsc_stream.cpp"]
+CLI = os.path.join(HERE, "bin", "atsc")
+CLI_SRC = "atsc_cli.cpp"
 DEPS = SOURCES + ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
 # -ffp-contract=off: the f64 spline / rounding arithmetic must evaluate exactly as written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -20,10 +22,10 @@ def _hipcc():
 
 
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(CLI))
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS + [CLI_SRC])
 
 
 def build(force=False, verbose=False):
@@ -33,6 +35,13 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    # the `atsc` command line front end (plain C++ over the C ABI)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cli = [_hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(CSRC, CLI_SRC), "-L" + HERE, "-latsc_hip",
+           "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cli))
+    subprocess.check_call(cli, cwd=CSRC)
     return LIB
 
 

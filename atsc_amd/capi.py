@@ -65,6 +65,24 @@ SIGNATURES = {
     "atsc_dplan_n_samples": (C.c_uint64, [_vp]),
     "atsc_decompress_plan_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "atsc_decompress_frames": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, _f64p, C.c_uint64, _u64p]),
+    "atsc_stream_new": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "atsc_stream_from_bytes": (C.c_int, [_vp, _u8p, C.c_uint64, C.POINTER(_vp)]),
+    "atsc_stream_free": (None, [_vp]),
+    "atsc_stream_compress_chunk": (C.c_int, [_vp, _f64p, C.c_uint64]),
+    "atsc_stream_compress_chunk_with": (C.c_int, [_vp, _f64p, C.c_uint64, C.c_int]),
+    "atsc_stream_compress_chunk_bounded_with": (C.c_int, [_vp, _f64p, C.c_uint64, C.c_int, C.c_float, C.c_int]),
+    "atsc_stream_frame_count": (C.c_uint64, [_vp]),
+    "atsc_stream_to_bytes": (C.c_int, [_vp, C.POINTER(_u8p), _u64p]),
+    "atsc_stream_decompress": (C.c_int, [_vp, C.POINTER(_f64p), _u64p]),
+    "atsc_free": (None, [_vp]),
+    "atsc_compress_data": (C.c_int, [_vp, _f64p, C.c_uint64, C.c_int, C.c_uint8, C.c_int, C.POINTER(_u8p), _u64p]),
+    "atsc_decompress_data": (C.c_int, [_vp, _u8p, C.c_uint64, C.POINTER(_f64p), _u64p]),
+    "atsc_wbro_from_bytes": (C.c_int, [_u8p, C.c_uint64, C.POINTER(_f64p), _u64p]),
+    "atsc_wbro_to_bytes": (C.c_int, [_f64p, C.c_uint64, C.POINTER(_u8p), _u64p]),
+    "atsc_wbro_read": (C.c_int, [C.c_char_p, C.POINTER(_f64p), _u64p]),
+    "atsc_wbro_write": (C.c_int, [C.c_char_p, _f64p, C.c_uint64]),
+    "atsc_bro_read_file": (C.c_int, [C.c_char_p, C.POINTER(_u8p), _u64p]),
+    "atsc_csv_read": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(_f64p), _u64p]),
     "atsc_chunk_sizes": (C.c_uint64, [C.c_uint64, _u64p, C.c_uint64]),
     "atsc_clean_data": (C.c_uint64, [_f64p, C.c_uint64, _f64p]),
     "atsc_next_size": (C.c_uint64, [C.c_uint64]),

@@ -1,0 +1,500 @@
+// atsc_stream.cpp -- host side above the batch ABI: the reference's calling surface restated in C++
+// (Rust is not available in this image): CompressedStream (atsc/src/data.rs), compress_data /
+// decompress_data (atsc/src/main.rs:130-172), WBRO files (wavbrro/src/*.rs), BRO file sniffing
+// (atsc/src/utils/readers/bro_reader.rs) and the CSV reader (atsc/src/csv.rs).  All compression goes
+// through atsc_compress_frames / atsc_decompress_frames, i.e. the GPU; nothing here computes a codec.
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/atsc_hip.h"
+
+namespace {
+
+uint32_t put_varint(uint8_t *p, uint64_t v)
+{
+    if (v < 251) { p[0] = (uint8_t)v; return 1; }
+    uint32_t nb;
+    if (v < (1ull << 16)) { p[0] = 251; nb = 2; }
+    else if (v < (1ull << 32)) { p[0] = 252; nb = 4; }
+    else { p[0] = 253; nb = 8; }
+    for (uint32_t i = 0; i < nb; ++i) p[1 + i] = (uint8_t)(v >> (8 * i));
+    return nb + 1;
+}
+bool get_varint(const uint8_t *b, uint64_t len, uint64_t &pos, uint64_t &v)
+{
+    if (pos >= len) return false;
+    const uint8_t t = b[pos];
+    uint32_t nb;
+    if (t < 251) { v = t; pos += 1; return true; }
+    if (t == 251) nb = 2;
+    else if (t == 252) nb = 4;
+    else if (t == 253) nb = 8;
+    else return false;
+    if (pos + 1 + nb > len) return false;
+    v = 0;
+    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)b[pos + 1 + i] << (8 * i);
+    pos += 1 + nb;
+    return true;
+}
+
+struct Item {
+    // an encoded frame record (varint(41) varint(n) varint(tag) varint(len) payload) ...
+    std::vector<uint8_t> record;
+    // ... or a queued chunk waiting for the GPU batch
+    std::vector<double> chunk;
+    int compressor = 0, bounded = 0, level = 0;
+    float max_error = 0.0f;
+    bool pending = false;
+};
+
+}  // namespace
+
+struct atsc_stream {
+    atsc_ctx *ctx = nullptr;
+    std::vector<Item> items;
+};
+
+extern "C" void atsc_free(void *p) { free(p); }
+
+extern "C" int atsc_stream_new(atsc_ctx *ctx, atsc_stream **out)
+{
+    if (!ctx || !out) return ATSC_E_INVALID;
+    atsc_stream *s = new (std::nothrow) atsc_stream();
+    if (!s) return ATSC_E_NOMEM;
+    s->ctx = ctx;
+    *out = s;
+    return ATSC_OK;
+}
+extern "C" void atsc_stream_free(atsc_stream *s) { delete s; }
+extern "C" uint64_t atsc_stream_frame_count(const atsc_stream *s) { return s ? s->items.size() : 0; }
+
+static int queue_chunk(atsc_stream *s, const double *chunk, uint64_t n, int compressor, int bounded,
+                       float max_error, int level)
+{
+    if (!s || !chunk || n == 0) return ATSC_E_INVALID;
+    if (compressor < 0 || compressor > 6) return ATSC_E_INVALID;
+    if (compressor == ATSC_AUTO && !bounded) return ATSC_E_INVALID;  // compressor/mod.rs:72 todo!()
+    if (level < 0 || level > 6) return ATSC_E_INVALID;
+    Item it;
+    it.chunk.assign(chunk, chunk + n);
+    it.compressor = compressor;
+    it.bounded = bounded;
+    it.max_error = max_error;
+    it.level = level;
+    it.pending = true;
+    s->items.push_back(std::move(it));
+    return ATSC_OK;
+}
+extern "C" int atsc_stream_compress_chunk(atsc_stream *s, const double *chunk, uint64_t n)
+{
+    return queue_chunk(s, chunk, n, ATSC_NOOP, 0, 0.0f, 0);
+}
+extern "C" int atsc_stream_compress_chunk_with(atsc_stream *s, const double *chunk, uint64_t n, int compressor)
+{
+    return queue_chunk(s, chunk, n, compressor, 0, 0.0f, 0);
+}
+extern "C" int atsc_stream_compress_chunk_bounded_with(atsc_stream *s, const double *chunk, uint64_t n,
+                                                       int compressor, float max_error, int compression_speed)
+{
+    // data.rs:68-72: Auto -> compress_best, everything else -> compress_bounded
+    return queue_chunk(s, chunk, n, compressor, 1, max_error, compression_speed);
+}
+
+// Runs every queued chunk through the GPU, one batch per distinct (compressor, bounded, error, level).
+static int flush(atsc_stream *s)
+{
+    typedef std::tuple<int, int, uint32_t, int> Key;
+    std::map<Key, std::vector<size_t>> groups;
+    for (size_t i = 0; i < s->items.size(); ++i) {
+        const Item &it = s->items[i];
+        if (!it.pending) continue;
+        uint32_t eb;
+        memcpy(&eb, &it.max_error, 4);
+        groups[Key(it.compressor, it.bounded, eb, it.level)].push_back(i);
+    }
+    for (auto &g : groups) {
+        const std::vector<size_t> &idx = g.second;
+        std::vector<uint64_t> off(idx.size() + 1, 0);
+        for (size_t k = 0; k < idx.size(); ++k) off[k + 1] = off[k] + s->items[idx[k]].chunk.size();
+        std::vector<double> flat(off.back());
+        uint64_t cap = 0;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const std::vector<double> &c = s->items[idx[k]].chunk;
+            memcpy(flat.data() + off[k], c.data(), c.size() * sizeof(double));
+            cap += atsc_payload_bound_bytes(c.size()) + 16;
+        }
+        std::vector<uint8_t> body(cap);
+        std::vector<uint64_t> rec_off(idx.size() + 1);
+        uint64_t blen = 0;
+        const Item &first = s->items[idx[0]];
+        int rc = atsc_compress_frames(s->ctx, flat.data(), off.data(), idx.size(), first.compressor,
+                                      first.bounded, first.max_error, first.level, body.data(), cap, &blen,
+                                      rec_off.data(), nullptr, nullptr);
+        if (rc) return rc;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            Item &it = s->items[idx[k]];
+            it.record.assign(body.begin() + rec_off[k], body.begin() + rec_off[k + 1]);
+            it.pending = false;
+            std::vector<double>().swap(it.chunk);
+        }
+    }
+    return ATSC_OK;
+}
+
+extern "C" int atsc_stream_to_bytes(atsc_stream *s, uint8_t **out, uint64_t *len)
+{
+    if (!s || !out || !len) return ATSC_E_INVALID;
+    int rc = flush(s);
+    if (rc) return rc;
+    uint64_t total = 18;
+    for (const Item &it : s->items) total += it.record.size();
+    uint8_t *buf = (uint8_t *)malloc(total);
+    if (!buf) return ATSC_E_NOMEM;
+    uint64_t pos = atsc_bro_prefix(s->items.size(), buf);  // header.rs:60-67 + data.rs:83
+    for (const Item &it : s->items) {
+        memcpy(buf + pos, it.record.data(), it.record.size());
+        pos += it.record.size();
+    }
+    *out = buf;
+    *len = pos;
+    return ATSC_OK;
+}
+
+extern "C" int atsc_stream_from_bytes(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, atsc_stream **out)
+{
+    if (!ctx || !bro || !out) return ATSC_E_INVALID;
+    uint64_t pos = 0, nf = 0;
+    int rc = atsc_bro_open(bro, len, &pos, &nf);
+    if (rc) return rc;
+    atsc_stream *s = new (std::nothrow) atsc_stream();
+    if (!s) return ATSC_E_NOMEM;
+    s->ctx = ctx;
+    for (uint64_t f = 0; f < nf; ++f) {
+        const uint64_t start = pos;
+        uint64_t fs, sc, tag, dl;
+        if (!get_varint(bro, len, pos, fs) || !get_varint(bro, len, pos, sc) || !get_varint(bro, len, pos, tag) ||
+            !get_varint(bro, len, pos, dl) || pos + dl > len) {
+            delete s;
+            return ATSC_E_FORMAT;  // bincode decode .unwrap() (data.rs:98)
+        }
+        pos += dl;
+        Item it;
+        it.record.assign(bro + start, bro + pos);
+        s->items.push_back(std::move(it));
+    }
+    *out = s;
+    return ATSC_OK;
+}
+
+extern "C" int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n)
+{
+    if (!s || !out || !n) return ATSC_E_INVALID;
+    int rc = flush(s);
+    if (rc) return rc;
+    std::vector<uint8_t> body;
+    uint64_t samples = 0;
+    for (const Item &it : s->items) {
+        body.insert(body.end(), it.record.begin(), it.record.end());
+        uint64_t pos = 0, fs, sc = 0;
+        get_varint(it.record.data(), it.record.size(), pos, fs);
+        get_varint(it.record.data(), it.record.size(), pos, sc);
+        samples += sc;
+    }
+    *out = nullptr;
+    *n = 0;
+    if (s->items.empty()) { *out = (double *)malloc(8); return *out ? ATSC_OK : ATSC_E_NOMEM; }
+    // Noop frames decode to their stored count, not sample_count (noop.rs:79-83): ask the decoder
+    uint64_t cap = samples + 16;
+    double *buf = (double *)malloc(cap * sizeof(double));
+    if (!buf) return ATSC_E_NOMEM;
+    uint64_t got = 0;
+    rc = atsc_decompress_frames(s->ctx, body.data(), body.size(), 0, buf, cap, &got);
+    if (rc == ATSC_E_CAPACITY) {
+        free(buf);
+        cap = got;
+        buf = (double *)malloc((cap ? cap : 1) * sizeof(double));
+        if (!buf) return ATSC_E_NOMEM;
+        rc = atsc_decompress_frames(s->ctx, body.data(), body.size(), 0, buf, cap, &got);
+    }
+    if (rc) { free(buf); return rc; }
+    *out = buf;
+    *n = got;
+    return ATSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// main.rs:130-172
+// ------------------------------------------------------------------------------------------
+extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n, int compressor,
+                                  uint8_t error_pct, int sample_level, uint8_t **bro, uint64_t *len)
+{
+    if (!ctx || (!data && n) || !bro || !len) return ATSC_E_INVALID;
+    std::vector<double> clean(n ? n : 1);
+    const uint64_t cn = atsc_clean_data(data, n, clean.data());          // optimizer/mod.rs:47-49
+    const uint64_t nch = atsc_chunk_sizes(cn, nullptr, 0);
+    std::vector<uint64_t> sizes(nch ? nch : 1);
+    atsc_chunk_sizes(cn, sizes.data(), nch);
+    atsc_stream *s = nullptr;
+    int rc = atsc_stream_new(ctx, &s);
+    if (rc) return rc;
+    const bool lossy = compressor == ATSC_FFT || compressor == ATSC_POLYNOMIAL || compressor == ATSC_IDW ||
+                       compressor == ATSC_AUTO;                            // main.rs:150-162
+    const float max_error = (float)error_pct / 100.0f;                     // main.rs:157
+    uint64_t off = 0;
+    for (uint64_t c = 0; c < nch && !rc; ++c) {
+        rc = lossy ? atsc_stream_compress_chunk_bounded_with(s, clean.data() + off, sizes[c], compressor,
+                                                             max_error, sample_level)
+                   : atsc_stream_compress_chunk_with(s, clean.data() + off, sizes[c], compressor);
+        off += sizes[c];
+    }
+    if (!rc) rc = atsc_stream_to_bytes(s, bro, len);
+    atsc_stream_free(s);
+    return rc;
+}
+
+extern "C" int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, double **out, uint64_t *n)
+{
+    atsc_stream *s = nullptr;
+    int rc = atsc_stream_from_bytes(ctx, bro, len, &s);
+    if (rc) return rc;
+    rc = atsc_stream_decompress(s, out, n);
+    atsc_stream_free(s);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// files
+// ------------------------------------------------------------------------------------------
+static int read_file(const char *path, std::vector<uint8_t> &buf)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return ATSC_E_IO;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); return ATSC_E_IO; }
+    buf.resize((size_t)sz);
+    const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return got == (size_t)sz ? ATSC_OK : ATSC_E_IO;
+}
+static int write_file(const char *path, const uint8_t *p, uint64_t len)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return ATSC_E_IO;
+    const size_t w = len ? fwrite(p, 1, len, f) : 0;
+    fclose(f);
+    return w == len ? ATSC_OK : ATSC_E_IO;
+}
+
+// rkyv 0.7.44 archive written by WavBrro::to_bytes (wavbrro.rs:126-132), layout per SURVEY App. B:
+//   [chunk 0 f64 data][chunk 1 ...] [n_chunks x {rel_off:i32, len:u32}] [root: {rel_off:i32,
+//   n_chunks:u32, sample_count:u32, bitdepth:u8, pad[3]}]   -- relative offsets are from the field
+extern "C" int atsc_wbro_to_bytes(const double *data, uint64_t n, uint8_t **out, uint64_t *len)
+{
+    if ((!data && n) || !out || !len) return ATSC_E_INVALID;
+    const uint64_t CH = 2048;  // MAX_CHUNK_SIZE, wavbrro.rs:24
+    const uint64_t nch = (n + CH - 1) / CH;
+    const uint64_t total = 12 + 8 * n + 8 * nch + 16;
+    uint8_t *buf = (uint8_t *)calloc(total, 1);
+    if (!buf) return ATSC_E_NOMEM;
+    memcpy(buf, "WBRO0000WBRO", 12);  // write.rs:22
+    uint8_t *body = buf + 12;
+    if (n) memcpy(body, data, 8 * n);
+    const uint64_t ent0 = 8 * n;
+    for (uint64_t c = 0; c < nch; ++c) {
+        const uint64_t ent = ent0 + 8 * c;
+        const int32_t rel = (int32_t)((int64_t)(8 * CH * c) - (int64_t)ent);
+        const uint32_t cl = (uint32_t)std::min<uint64_t>(CH, n - CH * c);
+        memcpy(body + ent, &rel, 4);
+        memcpy(body + ent + 4, &cl, 4);
+    }
+    const uint64_t root = ent0 + 8 * nch;
+    const int32_t rrel = (int32_t)((int64_t)ent0 - (int64_t)root);
+    const uint32_t nch32 = (uint32_t)nch, sc = (uint32_t)n;  // `sample_count as u32` (wavbrro.rs:81)
+    memcpy(body + root, &rrel, 4);
+    memcpy(body + root + 4, &nch32, 4);
+    memcpy(body + root + 8, &sc, 4);
+    body[root + 12] = 5;  // bitdepth: f64
+    *out = buf;
+    *len = total;
+    return ATSC_OK;
+}
+
+extern "C" int atsc_wbro_from_bytes(const uint8_t *file, uint64_t len, double **out, uint64_t *n)
+{
+    if (!file || !out || !n) return ATSC_E_INVALID;
+    if (len < 12 + 16 || memcmp(file, "WBRO", 4) != 0 || memcmp(file + 8, "WBRO", 4) != 0)
+        return ATSC_E_FORMAT;  // read.rs:23-29 -> Error::FormatError
+    const uint8_t *body = file + 12;
+    const uint64_t blen = len - 12;
+    const uint64_t root = blen - 16;
+    int32_t rrel;
+    uint32_t nch, sc;
+    memcpy(&rrel, body + root, 4);
+    memcpy(&nch, body + root + 4, 4);
+    memcpy(&sc, body + root + 8, 4);
+    const int64_t ent0 = (int64_t)root + rrel;
+    if (ent0 < 0 || (uint64_t)ent0 + 8ull * nch > root) return ATSC_E_FORMAT;
+    double *buf = (double *)malloc(((uint64_t)sc ? sc : 1) * sizeof(double));
+    if (!buf) return ATSC_E_NOMEM;
+    uint64_t k = 0;
+    for (uint32_t c = 0; c < nch; ++c) {
+        const int64_t ent = ent0 + 8ll * c;
+        int32_t rel;
+        uint32_t cl;
+        memcpy(&rel, body + ent, 4);
+        memcpy(&cl, body + ent + 4, 4);
+        const int64_t start = ent + rel;
+        if (start < 0 || (uint64_t)start + 8ull * cl > blen || k + cl > sc) { free(buf); return ATSC_E_FORMAT; }
+        memcpy(buf + k, body + start, 8ull * cl);
+        k += cl;
+    }
+    *out = buf;
+    *n = k;
+    return ATSC_OK;
+}
+extern "C" int atsc_wbro_read(const char *path, double **out, uint64_t *n)
+{
+    std::vector<uint8_t> buf;
+    int rc = read_file(path, buf);
+    if (rc) return rc;
+    return atsc_wbro_from_bytes(buf.data(), buf.size(), out, n);
+}
+extern "C" int atsc_wbro_write(const char *path, const double *data, uint64_t n)
+{
+    uint8_t *buf = nullptr;
+    uint64_t len = 0;
+    int rc = atsc_wbro_to_bytes(data, n, &buf, &len);
+    if (rc) return rc;
+    rc = write_file(path, buf, len);
+    free(buf);
+    return rc;
+}
+
+// utils/readers/bro_reader.rs:31-46: needs 12 readable bytes; a BRO file starts with "BRRO"
+extern "C" int atsc_bro_read_file(const char *path, uint8_t **out, uint64_t *len)
+{
+    if (!path || !out || !len) return ATSC_E_INVALID;
+    *out = nullptr;
+    *len = 0;
+    std::vector<uint8_t> buf;
+    int rc = read_file(path, buf);
+    if (rc) return rc;
+    if (buf.size() < 12) return ATSC_E_IO;  // read_exact on a 12-byte header fails
+    if (memcmp(buf.data(), "BRRO", 4) != 0) return ATSC_OK;  // Ok(None): not a BRO file, skipped
+    uint8_t *p = (uint8_t *)malloc(buf.size());
+    if (!p) return ATSC_E_NOMEM;
+    memcpy(p, buf.data(), buf.size());
+    *out = p;
+    *len = buf.size();
+    return ATSC_OK;
+}
+
+// Rust's `str::parse::<f64>` grammar: [+-]? ( "inf" | "infinity" | "nan" (any case) | digits [. digits?]
+// [e[+-]digits] | . digits [e...] ).  No surrounding whitespace, no hex.
+static bool parse_rust_f64(const std::string &s, double &v)
+{
+    size_t i = 0;
+    const size_t n = s.size();
+    if (n == 0) return false;
+    if (s[i] == '+' || s[i] == '-') ++i;
+    if (i >= n) return false;
+    std::string rest;
+    for (size_t k = i; k < n; ++k) rest.push_back((char)tolower((unsigned char)s[k]));
+    if (rest == "inf" || rest == "infinity" || rest == "nan") {
+        v = rest == "nan" ? NAN : (s[0] == '-' ? -INFINITY : INFINITY);
+        return true;
+    }
+    size_t digits = 0;
+    while (i < n && isdigit((unsigned char)s[i])) { ++i; ++digits; }
+    if (i < n && s[i] == '.') {
+        ++i;
+        while (i < n && isdigit((unsigned char)s[i])) { ++i; ++digits; }
+    }
+    if (digits == 0) return false;
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        ++i;
+        if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+        size_t ed = 0;
+        while (i < n && isdigit((unsigned char)s[i])) { ++i; ++ed; }
+        if (ed == 0) return false;
+    }
+    if (i != n) return false;
+    v = strtod(s.c_str(), nullptr);  // correctly rounded, as Rust's parser
+    return true;
+}
+
+// one CSV record -> fields (RFC 4180 quoting as the csv crate's default reader)
+static void split_csv(const std::string &line, std::vector<std::string> &f)
+{
+    f.clear();
+    std::string cur;
+    bool q = false;
+    for (size_t i = 0; i < line.size(); ++i) {
+        const char c = line[i];
+        if (q) {
+            if (c == '"' && i + 1 < line.size() && line[i + 1] == '"') { cur.push_back('"'); ++i; }
+            else if (c == '"') q = false;
+            else cur.push_back(c);
+        } else if (c == '"' && cur.empty()) q = true;
+        else if (c == ',') { f.push_back(cur); cur.clear(); }
+        else cur.push_back(c);
+    }
+    f.push_back(cur);
+}
+
+extern "C" int atsc_csv_read(const char *path, int has_header, const char *time_field, const char *value_field,
+                             double **out, uint64_t *n)
+{
+    if (!path || !out || !n) return ATSC_E_INVALID;
+    std::vector<uint8_t> buf;
+    int rc = read_file(path, buf);
+    if (rc) return rc;  // Error::OpenFileFailed
+    std::vector<std::string> lines;
+    {
+        std::string cur;
+        for (uint8_t c : buf) {
+            if (c == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
+            else cur.push_back((char)c);
+        }
+        if (!cur.empty()) lines.push_back(cur);
+    }
+    std::vector<std::string> f;
+    size_t li = 0, col = 0, width = 0;
+    while (li < lines.size() && lines[li].empty()) ++li;  // the csv crate skips empty lines
+    if (has_header) {
+        if (li >= lines.size()) return ATSC_E_FORMAT;
+        split_csv(lines[li++], f);
+        width = f.size();
+        bool have_t = false, have_v = false;
+        for (size_t k = 0; k < f.size(); ++k) {
+            if (time_field && !have_t && f[k] == time_field) have_t = true;
+            if (value_field && !have_v && f[k] == value_field) { have_v = true; col = k; }
+        }
+        if (!have_t || !have_v) return ATSC_E_FORMAT;  // TimestampFieldNotFound / ValueFieldNotFound
+    }
+    std::vector<double> vals;
+    for (; li < lines.size(); ++li) {
+        if (lines[li].empty()) continue;
+        split_csv(lines[li], f);
+        if (width == 0) width = f.size();
+        if (f.size() != width || col >= f.size()) return ATSC_E_FORMAT;  // csv: unequal record lengths
+        double v;
+        if (!parse_rust_f64(f[col], v)) return ATSC_E_FORMAT;  // Error::ParsingValueFailed
+        vals.push_back(v);
+    }
+    double *p = (double *)malloc((vals.size() ? vals.size() : 1) * sizeof(double));
+    if (!p) return ATSC_E_NOMEM;
+    if (!vals.empty()) memcpy(p, vals.data(), vals.size() * sizeof(double));
+    *out = p;
+    *n = vals.size();
+    return ATSC_OK;
+}

@@ -162,6 +162,51 @@ int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len
                            double *out, uint64_t out_cap, uint64_t *out_n);
 
 /* ------------------------------------------------------------------------ */
+/* CompressedStream mirror (atsc/src/data.rs:29-110)                          */
+/* ------------------------------------------------------------------------ */
+/* The reference compresses each chunk when it is added.  Here chunks are copied and queued;
+ * the GPU batch runs when the bytes are asked for (atsc_stream_to_bytes) -- observable results are
+ * the same, one frame per call in call order. */
+int atsc_stream_new(atsc_ctx *ctx, atsc_stream **out);                           /* data.rs:30-35 */
+/* data.rs:89-103 ; ATSC_E_FORMAT / ATSC_E_VERSION where the reference panics (header.rs:34-37,72-74) */
+int atsc_stream_from_bytes(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, atsc_stream **out);
+void atsc_stream_free(atsc_stream *s);
+/* data.rs:37-44 : CompressorFrame::new(None) = the default compressor, Noop */
+int atsc_stream_compress_chunk(atsc_stream *s, const double *chunk, uint64_t n);
+/* data.rs:47-53 ; ATSC_AUTO here is `todo!()` in the reference -> ATSC_E_INVALID */
+int atsc_stream_compress_chunk_with(atsc_stream *s, const double *chunk, uint64_t n, int compressor);
+/* data.rs:56-76 */
+int atsc_stream_compress_chunk_bounded_with(atsc_stream *s, const double *chunk, uint64_t n,
+                                            int compressor, float max_error, int compression_speed);
+uint64_t atsc_stream_frame_count(const atsc_stream *s);
+/* data.rs:79-85 ; *out is malloc'd, release with atsc_free */
+int atsc_stream_to_bytes(atsc_stream *s, uint8_t **out, uint64_t *len);
+/* data.rs:104-109 ; *out is malloc'd, release with atsc_free */
+int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n);
+void atsc_free(void *p);
+
+/* compress_data / decompress_data of the atsc CLI (atsc/src/main.rs:130-172): clean (drop NaN/Inf),
+ * chunk, compress every chunk with `compressor` (bounded with (float)error_pct/100 for
+ * fft/polynomial/idw/auto, unbounded for noop/constant/rle), whole .bro image out. */
+int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n, int compressor, uint8_t error_pct,
+                       int sample_level, uint8_t **bro, uint64_t *len);
+int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, double **out, uint64_t *n);
+
+/* WBRO files (wavbrro/src/wavbrro.rs:103-132, read.rs:23-37, write.rs:21-27):
+ * "WBRO0000WBRO" + rkyv 0.7.44 archive of {sample_count:u32, bitdepth:u8 = 5, chunks:Vec<Vec<f64>>}
+ * (chunks of 2048 samples).  Byte-identical to the reference's writer. */
+int atsc_wbro_from_bytes(const uint8_t *file, uint64_t len, double **out, uint64_t *n);
+int atsc_wbro_to_bytes(const double *data, uint64_t n, uint8_t **out, uint64_t *len);
+int atsc_wbro_read(const char *path, double **out, uint64_t *n);
+int atsc_wbro_write(const char *path, const double *data, uint64_t n);
+/* utils/readers/bro_reader.rs:31-46 : *out = NULL and rc 0 when the file is not a BRO file */
+int atsc_bro_read_file(const char *path, uint8_t **out, uint64_t *len);
+/* atsc/src/csv.rs:36-98 : value column of a comma separated file.  has_header != 0: both field names
+ * must be present, values come from value_field; else column 0.  Values parse as Rust's str::parse::<f64>. */
+int atsc_csv_read(const char *path, int has_header, const char *time_field, const char *value_field,
+                  double **out, uint64_t *n);
+
+/* ------------------------------------------------------------------------ */
 /* host-side format helpers (no GPU needed)                                 */
 /* ------------------------------------------------------------------------ */
 
