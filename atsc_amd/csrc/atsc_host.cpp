@@ -478,7 +478,8 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
             u.sample_off0 = f0.sample_off;
             u.slot_off0 = f0.slot_off;
             u.slot_stride = stride;
-            u.plan = p->tabs.plans[f0.plan];
+            u.n = f0.n;
+            u.plan = f0.plan;
         }
     }
     int rc = upload_tables(ctx, p->tabs);

@@ -63,16 +63,16 @@ struct KParams {
 };
 
 // Uniform launch: every frame of the class has the same length and frame f of the class sits at
-// sample_off0 + f*n with its slot at slot_off0 + f*slot_stride.  The per-length table then travels
-// by value in the kernel arguments, which removes the ids -> frames -> plans dependent loads from
-// the start of every workgroup.
+// sample_off0 + f*n with its slot at slot_off0 + f*slot_stride; the frame descriptor is then
+// computed instead of being loaded through ids[] -> frames[] (two dependent loads per workgroup).
 struct UniArgs {
     uint32_t enabled;
     uint32_t fid0;
     uint64_t sample_off0;
     uint64_t slot_off0;
     uint64_t slot_stride;
-    DevPlan plan;
+    uint32_t n;
+    uint32_t plan;
 };
 
 // parsed frame record for decompression

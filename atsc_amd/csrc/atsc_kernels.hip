@@ -168,7 +168,7 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // --------------------------------------------------------------------------------------------
 // the frame kernel
 // --------------------------------------------------------------------------------------------
-template <int W, int SPL>
+template <int W, int SPL, bool IDW>
 __global__ __launch_bounds__(64 * W) void k_compress(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
@@ -182,15 +182,15 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     DevFrame fr;
     if (uni.enabled) {
         fid = uni.fid0 + blockIdx.x;
-        fr.sample_off = uni.sample_off0 + (uint64_t)blockIdx.x * uni.plan.n;
+        fr.sample_off = uni.sample_off0 + (uint64_t)blockIdx.x * uni.n;
         fr.slot_off = uni.slot_off0 + (uint64_t)blockIdx.x * uni.slot_stride;
-        fr.n = uni.plan.n;
-        fr.plan = 0;
+        fr.n = uni.n;
+        fr.plan = uni.plan;
     } else {
         fid = ids[blockIdx.x];
         fr = frames[fid];
     }
-    const DevPlan &P = uni.enabled ? uni.plan : plans[fr.plan];
+    const DevPlan &P = plans[fr.plan];
     const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins;
 
     double *xs = (double *)(smem + P.o_xs);
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
     const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL || mode == ATSC_IDW);
     const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
-    const bool idw = (mode == ATSC_IDW);  // polynomial.rs:29-34,202-207: same codec, other interpolation
+    // polynomial.rs:29-34,202-207: Idw is the same codec with another interpolation; it is only
+    // reachable as a forced codec and is compiled as its own instantiation (IDW)
+    const bool idw = IDW && (mode == ATSC_IDW);
     const double me = prm.max_err;
     // RLE reports error 0.0: it passes, and bounds the others, exactly when 0.0 <= max_error
     const bool prune = (mode == ATSC_AUTO) && (0.0 <= me);
@@ -437,345 +439,334 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
     }
 
-    // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
-    bool poly_first = false;
-    if (prune && run_fft && run_poly && smax != smin) {
-        const uint32_t base0 = (3 >= n / 100) ? 3 : n / 100;
-        const uint32_t step0 = max(n / base0, 1u);
-        const uint32_t cnt0 = (n + step0 - 1) / step0;
-        const uint32_t K0 = cnt0 + (((cnt0 - 1) * step0 != n - 1) ? 1u : 0u);
-        poly_first = poly_payload_size(step0, K0) < 1 + 1 + 9 * min(P.mf, bins) + 8;
-    }
-    for (int ph = 0; ph < 2; ++ph) {
-        if ((ph == 0) != poly_first) {
-            // =========================================================================================
-            // FFT candidate: fft.rs:288-362
-            // =========================================================================================
-            if (run_fft) {
-                if (mxf == mnf) {
-                    fft_k = 0;  // fft.rs:289-292 ; error None -> 0.0 (fft.rs:523)
-                    fft_size = 1 + 1 + 8;
-                    fft_done = true;
-                } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
-                    // even a single stored bin is larger than a payload that already passes
-                } else {
-                    float2 *spec;
-                    if (P.direct) {
-                        dft_direct<W>(P, xs, A, tw);
-                        spec = A;
-                    } else if (P.half) {
-                        float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
-        #pragma unroll
-                        for (int m = 0; m < SPL; ++m) {
-                            const uint32_t j = tid + m * T;
-                            if (j < L) Af[j] = (float)g[m];
-                        }
-                        __syncthreads();
-                        float2 *Z = fft_forward<W>(P, A, B, tw);
-                        spec = (Z == A) ? B : A;
-                        fft_untangle<W>(P, Z, spec, tw);
-                    } else {
-        #pragma unroll
-                        for (int m = 0; m < SPL; ++m) {
-                            const uint32_t j = tid + m * T;
-                            if (j < L) A[j] = make_float2((float)g[m], 0.0f);
-                        }
-                        __syncthreads();
-                        spec = fft_forward<W>(P, A, B, tw);
+    // =========================================================================================
+    // FFT candidate: fft.rs:288-362
+    // =========================================================================================
+    if (run_fft) {
+        if (mxf == mnf) {
+            fft_k = 0;  // fft.rs:289-292 ; error None -> 0.0 (fft.rs:523)
+            fft_size = 1 + 1 + 8;
+            fft_done = true;
+        } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
+            // even a single stored bin is larger than a payload that already passes
+        } else {
+            float2 *spec;
+            if (P.direct) {
+                dft_direct<W>(P, xs, A, tw);
+                spec = A;
+            } else if (P.half) {
+                float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) Af[j] = (float)g[m];
+                }
+                __syncthreads();
+                float2 *Z = fft_forward<W>(P, A, B, tw);
+                spec = (Z == A) ? B : A;
+                fft_untangle<W>(P, Z, spec, tw);
+            } else {
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) A[j] = make_float2((float)g[m], 0.0f);
+                }
+                __syncthreads();
+                spec = fft_forward<W>(P, A, B, tw);
+            }
+            if (prm.debug_stop == 4) return;
+            // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
+            // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
+            // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
+            // W > 1: one sort of 64-bit keys up front.
+            constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
+            uint32_t nb[KPL];
+            uint64_t *keys = (uint64_t *)(spec == A ? B : A);
+            uint32_t nz = 0;
+            if (W == 1) {
+#pragma unroll
+                for (int m = 0; m < KPL; ++m) {
+                    const uint32_t k = tid + 64 * m;
+                    nb[m] = 0;
+                    if (k < bins) {
+                        const float2 z = spec[k];
+                        nb[m] = __float_as_uint(
+                            (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+                        nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
                     }
-                    if (prm.debug_stop == 4) return;
-                    // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
-                    // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
-                    // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
-                    // W > 1: one sort of 64-bit keys up front.
-                    constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
-                    uint32_t nb[KPL];
-                    uint64_t *keys = (uint64_t *)(spec == A ? B : A);
-                    uint32_t nz = 0;
-                    if (W == 1) {
-        #pragma unroll
-                        for (int m = 0; m < KPL; ++m) {
-                            const uint32_t k = tid + 64 * m;
-                            nb[m] = 0;
-                            if (k < bins) {
-                                const float2 z = spec[k];
-                                nb[m] = __float_as_uint(
-                                    (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
-                                nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                            }
-                        }
-                    } else {
-                        for (uint32_t k = tid; k < bins; k += T) {
-                            const float2 z = spec[k];
-                            const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-                            keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
-                            nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                        }
-                        __syncthreads();
-                    }
-                    const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
-                    if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
+                }
+            } else {
+                for (uint32_t k = tid; k < bins; k += T) {
+                    const float2 z = spec[k];
+                    const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                    keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
+                    nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                }
+                __syncthreads();
+            }
+            const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
+            if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
 
-                    if (prm.debug_stop == 5) return;
-                    bool fft_pruned = false;
-                    float acc[SPL];
-        #pragma unroll
-                    for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
-                    float dc = 0.0f;
-                    const double mxd = (double)mxf, mnd = (double)mnf;
-                    const double Ld = (double)L;
-                    const double invL = 1.0 / Ld;
-                    const uint32_t magicL = P.magicL;
-                    uint32_t used = 0, jump = 0, big = 0;
-                    double cur = prm.max_err + 1.0;
-                    // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
-                    // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
-                    while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
-                        const uint32_t K = min(P.mf + jump, Z);
-                        if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
-                        ++fft_trips;
-                        for (; used < K; ++used) {
-                            uint32_t pos;
-                            if (W == 1) {
-                                uint32_t lm = nb[0];
-        #pragma unroll
-                                for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
-                                const uint32_t wm = wave_max_u32(lm);
-                                uint32_t cand = 0xFFFFFFFFu;
-        #pragma unroll
-                                for (int m = KPL - 1; m >= 0; --m)
-                                    if (nb[m] == wm) cand = tid + 64 * m;
-                                pos = wave_min_u32(cand);
-        #pragma unroll
-                                for (int m = 0; m < KPL; ++m)
-                                    if (tid + 64 * m == pos) nb[m] = 0;
-                            } else {
-                                pos = (uint32_t)(keys[used] & 0xffffffffu);
-                            }
-                            const float2 z = spec[pos];
-                            if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
-                            big += (pos >= 251) ? 1u : 0u;
-                            // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
-                            // the 1/L of fft.rs:343 is folded into the coefficient
-                            const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
-                            const float a = (float)(cf * (double)z.x);
-                            const float b = (float)(cf * (double)z.y);
-                            if (pos == 0) {
-                                dc = a;
-                            } else {
-                                uint32_t idx = mod_magic(pos * tid, L, magicL);
-                                const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
-        #pragma unroll
-                                for (int m = 0; m < SPL; ++m) {
-                                    if (tid + m * T < L) {
-                                        const float2 w = tw[idx];
-                                        acc[m] = fmaf(a, w.x, acc[m]);
-                                        acc[m] = fmaf(-b, w.y, acc[m]);
-                                    }
-                                    idx += stp;
-                                    if (idx >= L) idx -= L;
-                                }
-                            }
-                        }
-                        if (!prm.bounded) { cur = 0.0; break; }
-                        double s = 0.0;
-        #pragma unroll
+            if (prm.debug_stop == 5) return;
+            bool fft_pruned = false;
+            float acc[SPL];
+#pragma unroll
+            for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
+            float dc = 0.0f;
+            const double mxd = (double)mxf, mnd = (double)mnf;
+            const double Ld = (double)L;
+            const double invL = 1.0 / Ld;
+            const uint32_t magicL = P.magicL;
+            uint32_t used = 0, jump = 0, big = 0;
+            double cur = prm.max_err + 1.0;
+            // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
+            // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
+            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
+                const uint32_t K = min(P.mf + jump, Z);
+                if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
+                ++fft_trips;
+                for (; used < K; ++used) {
+                    uint32_t pos;
+                    if (W == 1) {
+                        uint32_t lm = nb[0];
+#pragma unroll
+                        for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
+                        const uint32_t wm = wave_max_u32(lm);
+                        uint32_t cand = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int m = KPL - 1; m >= 0; --m)
+                            if (nb[m] == wm) cand = tid + 64 * m;
+                        pos = wave_min_u32(cand);
+#pragma unroll
+                        for (int m = 0; m < KPL; ++m)
+                            if (tid + 64 * m == pos) nb[m] = 0;
+                    } else {
+                        pos = (uint32_t)(keys[used] & 0xffffffffu);
+                    }
+                    const float2 z = spec[pos];
+                    if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
+                    big += (pos >= 251) ? 1u : 0u;
+                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
+                    // the 1/L of fft.rs:343 is folded into the coefficient
+                    const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
+                    const float a = (float)(cf * (double)z.x);
+                    const float b = (float)(cf * (double)z.y);
+                    if (pos == 0) {
+                        dc = a;
+                    } else {
+                        uint32_t idx = mod_magic(pos * tid, L, magicL);
+                        const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
+#pragma unroll
                         for (int m = 0; m < SPL; ++m) {
                             if (tid + m * T < L) {
-                                const double v = (double)(acc[m] + dc);
-                                double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
-                                if (o > mxd) o = mxd;
-                                if (o < mnd) o = mnd;
-                                s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
+                                const float2 w = tw[idx];
+                                acc[m] = fmaf(a, w.x, acc[m]);
+                                acc[m] = fmaf(-b, w.y, acc[m]);
+                            }
+                            idx += stp;
+                            if (idx >= L) idx -= L;
+                        }
+                    }
+                }
+                if (!prm.bounded) { cur = 0.0; break; }
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    if (tid + m * T < L) {
+                        const double v = (double)(acc[m] + dc);
+                        double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
+                        if (o > mxd) o = mxd;
+                        if (o < mnd) o = mnd;
+                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
+                    }
+                }
+                s = block_sum_f64<W>(s, red, parity);
+                cur = s / Ld;
+                if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
+                else if (fft_trips <= 22) jump += P.dk2;
+                else break;
+            }
+            fft_err = cur;
+            fft_k = used;
+            fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+            fft_done = !fft_pruned;
+            __syncthreads();  // sel[] is complete; AB may be reused from here on
+        }
+        if (prune && fft_done && fft_err <= me) offer(fft_size, 0);
+        dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
+        dg.fft_err = fft_err;
+    }
+
+
+    {   // (the FFT ladder runs first: one inlined copy of each ladder keeps the register count low)
+        // =========================================================================================
+        // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
+        // =========================================================================================
+        if (run_poly) {
+            bool poly_pruned = false;
+            if (smax == smin) {
+                poly_K = 0;  // polynomial.rs:210-213
+                poly_step = 1;
+            } else if (!prm.bounded) {
+                // Compressor::compress -> polynomial() -> compress_hinted(baseline points), no error loop
+                // (polynomial.rs:307-314,407-413)
+                const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+                poly_step = max(n / base, 1u);
+                const uint32_t cnt = (n + poly_step - 1) / poly_step;
+                poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
+            } else {
+                const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+                const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+                double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
+                double cur = prm.max_err + 1.0;
+                uint32_t jump = 0;
+                while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
+                    const uint32_t pts = base + jump;
+                    const uint32_t step = max(n / pts, 1u);
+                    const uint32_t cnt = (n + step - 1) / step;
+                    const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                    if (prune && !can_win(poly_payload_size(step, K), 1)) { poly_pruned = true; break; }
+                    ++poly_trips;
+                    poly_step = step;
+                    poly_K = K;
+                    if (IDW && step > 1 && idw) {
+                        // polynomial.rs:375-393 + inverse_distance_weight 0.1.1 (oracle: poly_idw_to_data):
+                        // every sample sums over ALL K points in ascending order; an exact hit returns the
+                        // point's value.  O(n K) per trip, forced `--compressor idw` only.
+                        double s = 0.0;
+    #pragma unroll
+                        for (int m = 0; m < SPL; ++m) {
+                            const uint32_t j = tid + m * T;
+                            if (j >= pre && j < pre + n) {
+                                const double x = (double)(j - pre);
+                                double num = 0.0, den = 0.0, hitv = 0.0;
+                                bool hit = false;
+                                for (uint32_t k = 0; k < K; ++k) {
+                                    const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                                    const double v = xs[pk];
+                                    const double d = fabs((double)pk - x);
+                                    if (d == 0.0) {
+                                        if (!hit) { hit = true; hitv = v; }
+                                    } else if (!hit) {
+                                        const double w = 1.0 / (d * d);
+                                        num += w * v;
+                                        den += w;
+                                    }
+                                }
+                                const double sv = hit ? hitv : num / den;
+                                double o = div1e5(round(sv * 100000.0));
+                                if (o < smin) o = smin;
+                                else if (o > smax) o = smax;
+                                s += fabs(o - g[m]) * inv[m];
                             }
                         }
                         s = block_sum_f64<W>(s, red, parity);
-                        cur = s / Ld;
-                        if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
-                        else if (fft_trips <= 22) jump += P.dk2;
-                        else break;
-                    }
-                    fft_err = cur;
-                    fft_k = used;
-                    fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
-                    fft_done = !fft_pruned;
-                    __syncthreads();  // sel[] is complete; AB may be reused from here on
-                }
-                if (prune && fft_done && fft_err <= me) offer(fft_size, 0);
-                dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
-                dg.fft_err = fft_err;
-            }
-
-        } else {
-            // =========================================================================================
-            // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
-            // =========================================================================================
-            if (run_poly) {
-                bool poly_pruned = false;
-                if (smax == smin) {
-                    poly_K = 0;  // polynomial.rs:210-213
-                    poly_step = 1;
-                } else if (!prm.bounded) {
-                    // Compressor::compress -> polynomial() -> compress_hinted(baseline points), no error loop
-                    // (polynomial.rs:307-314,407-413)
-                    const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-                    poly_step = max(n / base, 1u);
-                    const uint32_t cnt = (n + poly_step - 1) / poly_step;
-                    poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
-                } else {
-                    const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-                    const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
-                    double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
-                    double cur = prm.max_err + 1.0;
-                    uint32_t jump = 0;
-                    while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
-                        const uint32_t pts = base + jump;
-                        const uint32_t step = max(n / pts, 1u);
-                        const uint32_t cnt = (n + step - 1) / step;
-                        const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
-                        if (prune && !can_win(poly_payload_size(step, K), 1)) { poly_pruned = true; break; }
-                        ++poly_trips;
-                        poly_step = step;
-                        poly_K = K;
-                        if (step > 1 && idw) {
-                            // polynomial.rs:375-393 + inverse_distance_weight 0.1.1 (oracle: poly_idw_to_data):
-                            // every sample sums over ALL K points in ascending order; an exact hit returns the
-                            // point's value.  O(n K) per trip, forced `--compressor idw` only.
-                            double s = 0.0;
-        #pragma unroll
-                            for (int m = 0; m < SPL; ++m) {
-                                const uint32_t j = tid + m * T;
-                                if (j >= pre && j < pre + n) {
-                                    const double x = (double)(j - pre);
-                                    double num = 0.0, den = 0.0, hitv = 0.0;
-                                    bool hit = false;
-                                    for (uint32_t k = 0; k < K; ++k) {
-                                        const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
-                                        const double v = xs[pk];
-                                        const double d = fabs((double)pk - x);
-                                        if (d == 0.0) {
-                                            if (!hit) { hit = true; hitv = v; }
-                                        } else if (!hit) {
-                                            const double w = 1.0 / (d * d);
-                                            num += w * v;
-                                            den += w;
-                                        }
-                                    }
-                                    const double sv = hit ? hitv : num / den;
-                                    double o = div1e5(round(sv * 100000.0));
-                                    if (o < smin) o = smin;
-                                    else if (o > smax) o = smax;
-                                    s += fabs(o - g[m]) * inv[m];
-                                }
-                            }
-                            s = block_sum_f64<W>(s, red, parity);
-                            cur = s / (double)n;
-                        } else if (step > 1) {
-                            // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
-                            // the first and the last one (polynomial.rs:349-353).  Everything that is the
-                            // same for all samples of a segment (the tangents m0, m1) or for all samples at
-                            // the same offset r inside a segment (the four Hermite basis values) is computed
-                            // once, in the crate's operation order (oracle: cubic_hermite), so each sample's
-                            // value keeps the oracle's bits.
-                            const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
-                            const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
-                            const double stepd = (double)step, gapLd = (double)gapL;
-                            const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
-                            const uint32_t mm_bytes = (16 * K + 15) & ~15u;
-                            const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= P.ab_bytes);
-                            double4 *hb = (double4 *)(AB + mm_bytes);  // basis (h00, h10, h01, h11) per offset r
-                            __syncthreads();
-                            for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
-                                const uint32_t t0i = sg * step;
-                                const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
-                                const uint32_t tmi = (sg - 1) * step;
-                                const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
-                                const double t0 = (double)t0i, t1 = (double)t1i;
-                                const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
-                                double2 t;
-                                t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
-                                t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
-                                mm[sg] = t;
-                            }
-                            if (use_tab) {
-                                for (uint32_t r = tid; r < step; r += T) {
-                                    const double nt = div_small((double)r, stepd, ry);
-                                    const double t2 = nt * nt;
-                                    const double t3 = t2 * nt;
-                                    const double two_t3 = t3 * 2.0;
-                                    const double two_t2 = t2 * 2.0;
-                                    const double three_t2 = t2 * 3.0;
-                                    double4 h;
-                                    h.x = two_t3 - three_t2 + 1.0;
-                                    h.y = t3 - two_t2 + nt;
-                                    h.z = three_t2 - two_t3;
-                                    h.w = t3 - t2;
-                                    hb[r] = h;
-                                }
-                            }
-                            __syncthreads();
-                            double s = 0.0;
-        #pragma unroll
-                            for (int m = 0; m < SPL; ++m) {
-                                const uint32_t j = tid + m * T;
-                                if (j >= pre && j < pre + n) {
-                                    const uint32_t i = j - pre;
-                                    double sv;
-                                    if (i == n - 1) {
-                                        sv = xs[n - 1];
-                                    } else {
-                                        uint32_t sg = __umulhi(i, magic);  // i / step
-                                        if (sg > K - 2) sg = K - 2;
-                                        const uint32_t t0i = sg * step;
-                                        const bool last = (sg == K - 2);
-                                        const uint32_t t1i = last ? (n - 1) : t0i + step;
-                                        const double v0 = xs[t0i], v1 = xs[t1i];
-                                        if (sg > 0 && !last) {  // Catmull-Rom: sg in 1..K-3
-                                            const double2 t = mm[sg];
-                                            if (use_tab) {
-                                                const double4 h = hb[i - t0i];
-                                                sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
-                                            } else {
-                                                const double nt = div_small((double)(i - t0i), stepd, ry);
-                                                const double t2 = nt * nt;
-                                                const double t3 = t2 * nt;
-                                                const double two_t3 = t3 * 2.0;
-                                                const double two_t2 = t2 * 2.0;
-                                                const double three_t2 = t2 * 3.0;
-                                                sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
-                                                     v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
-                                            }
-                                        } else {
-                                            const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
-                                                                        last ? ryL : ry);
-                                            sv = v0 * (1.0 - nt) + v1 * nt;
-                                        }
-                                    }
-                                    double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
-                                    if (o < smin) o = smin;
-                                    else if (o > smax) o = smax;
-                                    s += fabs(o - g[m]) * inv[m];
-                                }
-                            }
-                            s = block_sum_f64<W>(s, red, parity);
-                            cur = s / (double)n;
+                        cur = s / (double)n;
+                    } else if (step > 1) {
+                        // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
+                        // the first and the last one (polynomial.rs:349-353).  Everything that is the
+                        // same for all samples of a segment (the tangents m0, m1) or for all samples at
+                        // the same offset r inside a segment (the four Hermite basis values) is computed
+                        // once, in the crate's operation order (oracle: cubic_hermite), so each sample's
+                        // value keeps the oracle's bits.
+                        const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+                        const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
+                        const double stepd = (double)step, gapLd = (double)gapL;
+                        const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                        const uint32_t mm_bytes = (16 * K + 15) & ~15u;
+                        const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= P.ab_bytes);
+                        double4 *hb = (double4 *)(AB + mm_bytes);  // basis (h00, h10, h01, h11) per offset r
+                        __syncthreads();
+                        for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
+                            const uint32_t t0i = sg * step;
+                            const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                            const uint32_t tmi = (sg - 1) * step;
+                            const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                            const double t0 = (double)t0i, t1 = (double)t1i;
+                            const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+                            double2 t;
+                            t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                            t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                            mm[sg] = t;
                         }
-                        if (poly_trips <= 17) jump += dj1;
-                        else if (poly_trips <= 22) jump += dj2;
-                        else if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
-                        else { poly_step = 1; poly_K = n; cur = 0.0; break; }
-                        if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
+                        if (use_tab) {
+                            for (uint32_t r = tid; r < step; r += T) {
+                                const double nt = div_small((double)r, stepd, ry);
+                                const double t2 = nt * nt;
+                                const double t3 = t2 * nt;
+                                const double two_t3 = t3 * 2.0;
+                                const double two_t2 = t2 * 2.0;
+                                const double three_t2 = t2 * 3.0;
+                                double4 h;
+                                h.x = two_t3 - three_t2 + 1.0;
+                                h.y = t3 - two_t2 + nt;
+                                h.z = three_t2 - two_t3;
+                                h.w = t3 - t2;
+                                hb[r] = h;
+                            }
+                        }
+                        __syncthreads();
+                        double s = 0.0;
+    #pragma unroll
+                        for (int m = 0; m < SPL; ++m) {
+                            const uint32_t j = tid + m * T;
+                            if (j >= pre && j < pre + n) {
+                                const uint32_t i = j - pre;
+                                double sv;
+                                if (i == n - 1) {
+                                    sv = xs[n - 1];
+                                } else {
+                                    uint32_t sg = __umulhi(i, magic);  // i / step
+                                    if (sg > K - 2) sg = K - 2;
+                                    const uint32_t t0i = sg * step;
+                                    const bool last = (sg == K - 2);
+                                    const uint32_t t1i = last ? (n - 1) : t0i + step;
+                                    const double v0 = xs[t0i], v1 = xs[t1i];
+                                    if (sg > 0 && !last) {  // Catmull-Rom: sg in 1..K-3
+                                        const double2 t = mm[sg];
+                                        if (use_tab) {
+                                            const double4 h = hb[i - t0i];
+                                            sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
+                                        } else {
+                                            const double nt = div_small((double)(i - t0i), stepd, ry);
+                                            const double t2 = nt * nt;
+                                            const double t3 = t2 * nt;
+                                            const double two_t3 = t3 * 2.0;
+                                            const double two_t2 = t2 * 2.0;
+                                            const double three_t2 = t2 * 3.0;
+                                            sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
+                                                 v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
+                                        }
+                                    } else {
+                                        const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                                    last ? ryL : ry);
+                                        sv = v0 * (1.0 - nt) + v1 * nt;
+                                    }
+                                }
+                                double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
+                                if (o < smin) o = smin;
+                                else if (o > smax) o = smax;
+                                s += fabs(o - g[m]) * inv[m];
+                            }
+                        }
+                        s = block_sum_f64<W>(s, red, parity);
+                        cur = s / (double)n;
                     }
-                    poly_err = cur;
+                    if (poly_trips <= 17) jump += dj1;
+                    else if (poly_trips <= 22) jump += dj2;
+                    else if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
+                    else { poly_step = 1; poly_K = n; cur = 0.0; break; }
+                    if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
                 }
-                poly_size = poly_payload_size(poly_step, poly_K);
-                poly_done = !poly_pruned;
-                if (prune && poly_done && poly_err <= me) offer(poly_size, 1);
-                dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
-                dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
+                poly_err = cur;
             }
-
+            poly_size = poly_payload_size(poly_step, poly_K);
+            poly_done = !poly_pruned;
+            if (prune && poly_done && poly_err <= me) offer(poly_size, 1);
+            dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
+            dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
         }
+
     }
 
     // ---- RLE with many runs: exact size only if its bound can still win ----
@@ -1052,14 +1043,14 @@ __global__ __launch_bounds__(256) void k_pack_emit(
 // --------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------
-template <int W, int SPL>
-static hipError_t launch_class(uint32_t count, uint32_t lds, const double *samples,
+template <int W, int SPL, bool IDW>
+static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
                                DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
-    auto kern = k_compress<W, SPL>;
+    auto kern = k_compress<W, SPL, IDW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1068,6 +1059,17 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
     hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, samples, frames, ids, plans, twpool,
                        prm, slots, res, diag, uni);
     return hipGetLastError();
+}
+
+template <int W, int SPL>
+static hipError_t launch_class(uint32_t count, uint32_t lds, const double *samples,
+                               const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
+                               const float2 *twpool, const KParams &prm, uint8_t *slots,
+                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
+{
+    if (prm.mode == ATSC_IDW)
+        return launch_class2<W, SPL, true>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    return launch_class2<W, SPL, false>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
 }
 
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
