@@ -439,166 +439,16 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
     }
 
-    // =========================================================================================
-    // FFT candidate: fft.rs:288-362
-    // =========================================================================================
-    if (run_fft) {
-        if (mxf == mnf) {
-            fft_k = 0;  // fft.rs:289-292 ; error None -> 0.0 (fft.rs:523)
-            fft_size = 1 + 1 + 8;
-            fft_done = true;
-        } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
-            // even a single stored bin is larger than a payload that already passes
-        } else {
-            float2 *spec;
-            if (P.direct) {
-                dft_direct<W>(P, xs, A, tw);
-                spec = A;
-            } else if (P.half) {
-                float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
-#pragma unroll
-                for (int m = 0; m < SPL; ++m) {
-                    const uint32_t j = tid + m * T;
-                    if (j < L) Af[j] = (float)g[m];
-                }
-                __syncthreads();
-                float2 *Z = fft_forward<W>(P, A, B, tw);
-                spec = (Z == A) ? B : A;
-                fft_untangle<W>(P, Z, spec, tw);
-            } else {
-#pragma unroll
-                for (int m = 0; m < SPL; ++m) {
-                    const uint32_t j = tid + m * T;
-                    if (j < L) A[j] = make_float2((float)g[m], 0.0f);
-                }
-                __syncthreads();
-                spec = fft_forward<W>(P, A, B, tw);
-            }
-            if (prm.debug_stop == 4) return;
-            // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
-            // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
-            // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
-            // W > 1: one sort of 64-bit keys up front.
-            constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
-            uint32_t nb[KPL];
-            uint64_t *keys = (uint64_t *)(spec == A ? B : A);
-            uint32_t nz = 0;
-            if (W == 1) {
-#pragma unroll
-                for (int m = 0; m < KPL; ++m) {
-                    const uint32_t k = tid + 64 * m;
-                    nb[m] = 0;
-                    if (k < bins) {
-                        const float2 z = spec[k];
-                        nb[m] = __float_as_uint(
-                            (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
-                        nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                    }
-                }
-            } else {
-                for (uint32_t k = tid; k < bins; k += T) {
-                    const float2 z = spec[k];
-                    const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-                    keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
-                    nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                }
-                __syncthreads();
-            }
-            const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
-            if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
-
-            if (prm.debug_stop == 5) return;
-            bool fft_pruned = false;
-            float acc[SPL];
-#pragma unroll
-            for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
-            float dc = 0.0f;
-            const double mxd = (double)mxf, mnd = (double)mnf;
-            const double Ld = (double)L;
-            const double invL = 1.0 / Ld;
-            const uint32_t magicL = P.magicL;
-            uint32_t used = 0, jump = 0, big = 0;
-            double cur = prm.max_err + 1.0;
-            // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
-            // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
-            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
-                const uint32_t K = min(P.mf + jump, Z);
-                if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
-                ++fft_trips;
-                for (; used < K; ++used) {
-                    uint32_t pos;
-                    if (W == 1) {
-                        uint32_t lm = nb[0];
-#pragma unroll
-                        for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
-                        const uint32_t wm = wave_max_u32(lm);
-                        uint32_t cand = 0xFFFFFFFFu;
-#pragma unroll
-                        for (int m = KPL - 1; m >= 0; --m)
-                            if (nb[m] == wm) cand = tid + 64 * m;
-                        pos = wave_min_u32(cand);
-#pragma unroll
-                        for (int m = 0; m < KPL; ++m)
-                            if (tid + 64 * m == pos) nb[m] = 0;
-                    } else {
-                        pos = (uint32_t)(keys[used] & 0xffffffffu);
-                    }
-                    const float2 z = spec[pos];
-                    if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
-                    big += (pos >= 251) ? 1u : 0u;
-                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
-                    // the 1/L of fft.rs:343 is folded into the coefficient
-                    const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
-                    const float a = (float)(cf * (double)z.x);
-                    const float b = (float)(cf * (double)z.y);
-                    if (pos == 0) {
-                        dc = a;
-                    } else {
-                        uint32_t idx = mod_magic(pos * tid, L, magicL);
-                        const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
-#pragma unroll
-                        for (int m = 0; m < SPL; ++m) {
-                            if (tid + m * T < L) {
-                                const float2 w = tw[idx];
-                                acc[m] = fmaf(a, w.x, acc[m]);
-                                acc[m] = fmaf(-b, w.y, acc[m]);
-                            }
-                            idx += stp;
-                            if (idx >= L) idx -= L;
-                        }
-                    }
-                }
-                if (!prm.bounded) { cur = 0.0; break; }
-                double s = 0.0;
-#pragma unroll
-                for (int m = 0; m < SPL; ++m) {
-                    if (tid + m * T < L) {
-                        const double v = (double)(acc[m] + dc);
-                        double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
-                        if (o > mxd) o = mxd;
-                        if (o < mnd) o = mnd;
-                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
-                    }
-                }
-                s = block_sum_f64<W>(s, red, parity);
-                cur = s / Ld;
-                if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
-                else if (fft_trips <= 22) jump += P.dk2;
-                else break;
-            }
-            fft_err = cur;
-            fft_k = used;
-            fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
-            fft_done = !fft_pruned;
-            __syncthreads();  // sel[] is complete; AB may be reused from here on
-        }
-        if (prune && fft_done && fft_err <= me) offer(fft_size, 0);
-        dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
-        dg.fft_err = fft_err;
+    // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
+    bool poly_first = false;
+    if (prune && run_fft && run_poly && smax != smin) {
+        const uint32_t base0 = (3 >= n / 100) ? 3 : n / 100;
+        const uint32_t step0 = max(n / base0, 1u);
+        const uint32_t cnt0 = (n + step0 - 1) / step0;
+        const uint32_t K0 = cnt0 + (((cnt0 - 1) * step0 != n - 1) ? 1u : 0u);
+        poly_first = poly_payload_size(step0, K0) < 1 + 1 + 9 * min(P.mf, bins) + 8;
     }
-
-
-    {   // (the FFT ladder runs first: one inlined copy of each ladder keeps the register count low)
+    auto eval_poly = [&]() {
         // =========================================================================================
         // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
         // =========================================================================================
@@ -767,7 +617,169 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
         }
 
+    };
+
+    if (poly_first) eval_poly();
+    // =========================================================================================
+    // FFT candidate: fft.rs:288-362
+    // =========================================================================================
+    if (run_fft) {
+        if (mxf == mnf) {
+            fft_k = 0;  // fft.rs:289-292 ; error None -> 0.0 (fft.rs:523)
+            fft_size = 1 + 1 + 8;
+            fft_done = true;
+        } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
+            // even a single stored bin is larger than a payload that already passes
+        } else {
+            float2 *spec;
+            if (P.direct) {
+                dft_direct<W>(P, xs, A, tw);
+                spec = A;
+            } else if (P.half) {
+                float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) Af[j] = (float)g[m];
+                }
+                __syncthreads();
+                float2 *Z = fft_forward<W>(P, A, B, tw);
+                spec = (Z == A) ? B : A;
+                fft_untangle<W>(P, Z, spec, tw);
+            } else {
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) A[j] = make_float2((float)g[m], 0.0f);
+                }
+                __syncthreads();
+                spec = fft_forward<W>(P, A, B, tw);
+            }
+            if (prm.debug_stop == 4) return;
+            // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
+            // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
+            // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
+            // W > 1: one sort of 64-bit keys up front.
+            constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
+            uint32_t nb[KPL];
+            uint64_t *keys = (uint64_t *)(spec == A ? B : A);
+            uint32_t nz = 0;
+            if (W == 1) {
+#pragma unroll
+                for (int m = 0; m < KPL; ++m) {
+                    const uint32_t k = tid + 64 * m;
+                    nb[m] = 0;
+                    if (k < bins) {
+                        const float2 z = spec[k];
+                        nb[m] = __float_as_uint(
+                            (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+                        nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                    }
+                }
+            } else {
+                for (uint32_t k = tid; k < bins; k += T) {
+                    const float2 z = spec[k];
+                    const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                    keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
+                    nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                }
+                __syncthreads();
+            }
+            const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
+            if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
+
+            if (prm.debug_stop == 5) return;
+            bool fft_pruned = false;
+            float acc[SPL];
+#pragma unroll
+            for (int m = 0; m < SPL; ++m) acc[m] = 0.0f;
+            float dc = 0.0f;
+            const double mxd = (double)mxf, mnd = (double)mnf;
+            const double Ld = (double)L;
+            const double invL = 1.0 / Ld;
+            const uint32_t magicL = P.magicL;
+            uint32_t used = 0, jump = 0, big = 0;
+            double cur = prm.max_err + 1.0;
+            // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
+            // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
+            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
+                const uint32_t K = min(P.mf + jump, Z);
+                if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
+                ++fft_trips;
+                for (; used < K; ++used) {
+                    uint32_t pos;
+                    if (W == 1) {
+                        uint32_t lm = nb[0];
+#pragma unroll
+                        for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
+                        const uint32_t wm = wave_max_u32(lm);
+                        uint32_t cand = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int m = KPL - 1; m >= 0; --m)
+                            if (nb[m] == wm) cand = tid + 64 * m;
+                        pos = wave_min_u32(cand);
+#pragma unroll
+                        for (int m = 0; m < KPL; ++m)
+                            if (tid + 64 * m == pos) nb[m] = 0;
+                    } else {
+                        pos = (uint32_t)(keys[used] & 0xffffffffu);
+                    }
+                    const float2 z = spec[pos];
+                    if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
+                    big += (pos >= 251) ? 1u : 0u;
+                    // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
+                    // the 1/L of fft.rs:343 is folded into the coefficient
+                    const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
+                    const float a = (float)(cf * (double)z.x);
+                    const float b = (float)(cf * (double)z.y);
+                    if (pos == 0) {
+                        dc = a;
+                    } else {
+                        uint32_t idx = mod_magic(pos * tid, L, magicL);
+                        const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
+#pragma unroll
+                        for (int m = 0; m < SPL; ++m) {
+                            if (tid + m * T < L) {
+                                const float2 w = tw[idx];
+                                acc[m] = fmaf(a, w.x, acc[m]);
+                                acc[m] = fmaf(-b, w.y, acc[m]);
+                            }
+                            idx += stp;
+                            if (idx >= L) idx -= L;
+                        }
+                    }
+                }
+                if (!prm.bounded) { cur = 0.0; break; }
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    if (tid + m * T < L) {
+                        const double v = (double)(acc[m] + dc);
+                        double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
+                        if (o > mxd) o = mxd;
+                        if (o < mnd) o = mnd;
+                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
+                    }
+                }
+                s = block_sum_f64<W>(s, red, parity);
+                cur = s / Ld;
+                if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
+                else if (fft_trips <= 22) jump += P.dk2;
+                else break;
+            }
+            fft_err = cur;
+            fft_k = used;
+            fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+            fft_done = !fft_pruned;
+            __syncthreads();  // sel[] is complete; AB may be reused from here on
+        }
+        if (prune && fft_done && fft_err <= me) offer(fft_size, 0);
+        dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
+        dg.fft_err = fft_err;
     }
+
+
+    if (!poly_first) eval_poly();
 
     // ---- RLE with many runs: exact size only if its bound can still win ----
     if (run_rle && rle_pending) {
