@@ -238,17 +238,24 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
-        uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
-        for (uint32_t j = tid; j < n; j += T) {
-            const double v = xs[j];
-            if (v == mn) mni = min(mni, j);
-            if (v == mx) mxi = min(mxi, j);
-        }
-        mni = block_min_u32<W>(mni, red, parity);
-        mxi = block_min_u32<W>(mxi, red, parity);
         fr_any = block_or_u32<W>(fr_any, red, parity);
-        smin = (mni < n) ? xs[mni] : x0;  // x0 NaN: nothing compares, the scan keeps data[0]
-        smax = (mxi < n) ? xs[mxi] : x0;
+        // Samples that compare equal to the extreme value have the same bits, except for zeros
+        // (+0.0 == -0.0): only then the scan's "first occurrence" has to be looked up.  A NaN in
+        // data[0] poisons every compare and the scan keeps data[0] (mn, mx are x0 then).
+        smin = mn;
+        smax = mx;
+        if (mn == 0.0 || mx == 0.0) {
+            uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
+            for (uint32_t j = tid; j < n; j += T) {
+                const double v = xs[j];
+                if (v == mn) mni = min(mni, j);
+                if (v == mx) mxi = min(mxi, j);
+            }
+            mni = block_min_u32<W>(mni, red, parity);
+            mxi = block_min_u32<W>(mxi, red, parity);
+            if (mni < n) smin = xs[mni];
+            if (mxi < n) smax = xs[mxi];
+        }
         int64_t maxi, mini;
         bool fz;
         split_n(smax, maxi, fz);
@@ -302,21 +309,9 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         mode = (int)prm.trial_res[fid].chosen;
 
     if (prm.debug_stop == 2) return;
-    // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T
+    // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T.  Filled below,
+    // once it is known that a ladder will run at all.
     double g[SPL], inv[SPL];
-#pragma unroll
-    for (int m = 0; m < SPL; ++m) {
-        const uint32_t j = tid + m * T;
-        if (j < L) {
-            int32_t i = (int32_t)j - (int32_t)pre;
-            i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
-            g[m] = xs[i];
-            inv[m] = 1.0 / fabs(g[m]);
-        } else {
-            g[m] = 1.0;
-            inv[m] = 0.0;
-        }
-    }
 
     if (prm.debug_stop == 3) return;
     // =========================================================================================
@@ -367,6 +362,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     // ---- RLE (rle.rs:142-189): cheap bound first; exact right away when there are few runs ----
     uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0, rle_lb = 0xFFFFFFFFu;
     bool rle_sorted = false, rle_pending = false;
+    bool rle_early = false;  // the early run arrays in AB are still intact
     uint32_t *rrec_std = (uint32_t *)AB;        // 4n: run records (start << 16 | end), n <= 4096
     uint32_t *rhp_std = rrec_std + n;           // 4n+4: group head positions hp[0..D]
     uint32_t *rps = (uint32_t *)tw;             // 4n  prefix of index varint bytes (emission only)
@@ -432,10 +428,29 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             // few runs: size it now (AB is still free), so that it can stop the ladders early
             uint32_t *e_rec = (uint32_t *)AB;
             rle_sort_and_group(e_rec, e_rec + rle_R, e_rec + 2 * rle_R + 1);
-            rle_sorted = false;  // the ladders below reuse AB; the emitter sorts again if RLE wins
+            rle_sorted = false;  // the ladders below may reuse AB; the emitter sorts again unless rle_early survives
+            rle_early = true;
             if (prune) offer(rle_size, 2);
         } else {
             rle_pending = true;
+        }
+    }
+
+    // A payload below 19 bytes (FFT with one bin; Polynomial needs at least 23) already beats both
+    // ladders: skip loading their operands.
+    if (!(prune && best_size < 19)) {
+#pragma unroll
+        for (int m = 0; m < SPL; ++m) {
+            const uint32_t j = tid + m * T;
+            if (j < L) {
+                int32_t i = (int32_t)j - (int32_t)pre;
+                i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
+                g[m] = xs[i];
+                inv[m] = 1.0 / fabs(g[m]);
+            } else {
+                g[m] = 1.0;
+                inv[m] = 0.0;
+            }
         }
     }
 
@@ -519,6 +534,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                         // the same offset r inside a segment (the four Hermite basis values) is computed
                         // once, in the crate's operation order (oracle: cubic_hermite), so each sample's
                         // value keeps the oracle's bits.
+                        rle_early = false;  // the tangent / basis tables live in AB
                         const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
                         const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
                         const double stepd = (double)step, gapLd = (double)gapL;
@@ -631,6 +647,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
             // even a single stored bin is larger than a payload that already passes
         } else {
+            rle_early = false;  // AB is about to be overwritten
             float2 *spec;
             if (P.direct) {
                 dft_direct<W>(P, xs, A, tw);
@@ -906,8 +923,14 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         out_len = hdr + body + 17;
     } else {  // RLE: rle.rs:40-67
         // runs are sorted by (value bits, start); aux[i] = heads before i; rhp = hp[]; rph = hb[]
-        if (!rle_sorted) rle_sort_and_group(rrec_std, rhp_std, rph_std);
         uint32_t *rrec = rrec_std, *rhp = rhp_std, *rph = rph_std;
+        if (rle_early) {  // sized before the ladders, and no ladder touched AB since
+            rrec = (uint32_t *)AB;
+            rhp = rrec + rle_R;
+            rph = rrec + 2 * rle_R + 1;
+        } else if (!rle_sorted) {
+            rle_sort_and_group(rrec_std, rhp_std, rph_std);
+        }
         const uint32_t R = rle_R, D = rle_D;
         const uint32_t hdr = 2 + vlen(D);
         for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rrec[i] >> 16);

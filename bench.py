@@ -77,14 +77,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the compressor")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (never set by the driver): ATSC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # moves the record gather to gloo, so the N > 1 control flow can be exercised on a one-GPU box
+    # (RCCL refuses two ranks on one device).
+    share = os.environ.get("ATSC_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as G
 
@@ -95,7 +103,7 @@ def main():
     me = float(np.float32(ERROR_PCT) / np.float32(100))
     x = H.synth_series(rank, N_SAMPLES)
     off = H.frame_offsets(N_SAMPLES, FRAME)
-    ctx = atsc_amd.Context(local_rank)
+    ctx = atsc_amd.Context(dev_index)
     plan = ctx.plan(off)
     d_x = torch.from_numpy(x).to(dev)
     outs = plan.alloc_outputs(torch, dev)
@@ -110,8 +118,12 @@ def main():
         plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, stream)
         if world > 1:
             # the path's only exchange: concatenate the encoded records on rank 0
-            got, _ = parallel.gather_records(dist, torch, outs["body"], outs["rec_off"][-1:], rank,
-                                             world, sizes_dev, gstate["buf"])
+            if share:  # gloo moves host tensors
+                nb = int(outs["rec_off"][-1].item())
+                got, _ = parallel.gather_records(dist, torch, outs["body"][:nb].cpu(), nb, rank, world)
+            else:
+                got, _ = parallel.gather_records(dist, torch, outs["body"], outs["rec_off"][-1:], rank,
+                                                 world, sizes_dev, gstate["buf"])
             if rank == 0:
                 gstate["buf"] = got
 
@@ -133,13 +145,13 @@ def main():
     kern_ms, launches = ctx.profile_read()
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     body_bytes = int(outs["rec_off"][-1].item())
     if world > 1:
-        t = torch.tensor([body_bytes], dtype=torch.int64, device=dev)
+        t = torch.tensor([body_bytes], dtype=torch.int64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_body = int(t.item())
     else:
