@@ -111,37 +111,48 @@ def main():
 
     from atsc_amd import parallel
 
-    gstate = {"buf": None}
-    sizes_dev = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
+    # N > 1: two output sets so that the gather of step i overlaps the compression of step i+1
+    outs2 = [outs, plan.alloc_outputs(torch, dev)] if world > 1 else [outs]
+    pg = None
 
-    def step():
-        plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, stream)
+    def step(i):
+        o = outs2[i % len(outs2)]
+        if pg is not None:
+            pg.before_produce(i % 2)
+        plan.compress(d_x, o, atsc_amd.AUTO, True, me, 0, stream)
         if world > 1:
-            # the path's only exchange: concatenate the encoded records on rank 0
-            if share:  # gloo moves host tensors
-                nb = int(outs["rec_off"][-1].item())
-                got, _ = parallel.gather_records(dist, torch, outs["body"][:nb].cpu(), nb, rank, world)
+            # the path's only exchange: the encoded records go to rank 0
+            if pg is not None:
+                pg.submit(i % 2, o["body"], o["rec_off"][-1:])
+            elif share:  # rehearsal on one GPU: gloo moves host tensors
+                nb = int(o["rec_off"][-1].item())
+                parallel.gather_records(dist, torch, o["body"][:nb].cpu(), nb, rank, world)
             else:
-                got, _ = parallel.gather_records(dist, torch, outs["body"], outs["rec_off"][-1:], rank,
-                                                 world, sizes_dev, gstate["buf"])
-            if rank == 0:
-                gstate["buf"] = got
+                parallel.gather_records(dist, torch, o["body"], o["rec_off"][-1:], rank, world)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, 1 if world > 1 else 0)):
+        step(i)
     torch.cuda.synchronize()
+    if world > 1 and not share:
+        # segment capacity agreed once from the warm-up result; no host sync inside the timed loop
+        pg = parallel.PipelinedGather(dist, torch, rank, world, dev, int(outs2[0]["rec_off"][-1].item()))
     ctx.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    if pg is not None:
+        pg.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if pg is not None and rank == 0:
+        segs, sizes = pg.result((args.steps - 1) % 2)
+        assert len(segs) == world and sizes[0] == int(outs2[(args.steps - 1) % len(outs2)]["rec_off"][-1].item())
     kern_ms, launches = ctx.profile_read()
     ctx.set_profiling(False)
     if world > 1:

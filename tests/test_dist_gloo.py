@@ -51,6 +51,48 @@ def _worker(rank, world, port, n_frames, q):
     dist.destroy_process_group()
 
 
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from atsc_amd import parallel as P
+
+    dev = torch.device("cpu")
+    steps = 5
+    # per-step payloads differ in content and (slightly) in size, as real steps could
+    payload = lambda i: _fake_records(range(rank * 100 + i, rank * 100 + i + 40 + rank))
+    pg = P.PipelinedGather(dist, torch, rank, world, dev, len(payload(0)) + 8)
+    bufs = [torch.zeros(pg.cap + 64, dtype=torch.uint8) for _ in range(2)]
+    for i in range(steps):
+        pg.before_produce(i % 2)
+        rec = payload(i)
+        bufs[i % 2][: len(rec)] = torch.frombuffer(bytearray(rec), dtype=torch.uint8)
+        pg.submit(i % 2, bufs[i % 2], torch.tensor([len(rec)], dtype=torch.int64))
+    pg.drain()
+    if rank == 0:
+        segs, sizes = pg.result((steps - 1) % 2)
+        q.put((b"".join(bytes(s.numpy().tobytes()) for s in segs), sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_gather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, sizes = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = b"".join(_fake_records(range(r * 100 + 4, r * 100 + 4 + 40 + r)) for r in range(world))
+    assert got == want and sum(sizes) == len(want)
+
+
 @pytest.mark.parametrize("world,n_frames", [(2, 11), (2, 40960), (3, 10)])
 def test_gather_records_gloo(world, n_frames):
     ctx = mp.get_context("spawn")
