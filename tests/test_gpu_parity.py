@@ -467,3 +467,59 @@ def test_roundtrip_long_series_e2e(ctx, A, oracle):
     assert len(out) == len(x) == len(ref)
     assert H.mape(x, out) <= ME5 and H.mape(x, ref) <= ME5
     assert np.max(np.abs(out - ref)) <= 30 * 1300 * 2.0 ** -23
+
+
+# ---------------------------------------------------------------------------------------
+# randomized sweep: many generators x lengths x error bounds
+# ---------------------------------------------------------------------------------------
+def _fuzz_frame(rng, n):
+    kind = rng.integers(0, 12)
+    t = np.arange(n, dtype=np.float64)
+    if kind == 0:   # random walk
+        v = 500.0 + np.cumsum(rng.normal(0, 1, n))
+    elif kind == 1:  # steps / plateaus
+        v = np.repeat(rng.integers(1, 2000, max(n // 7, 1) + 1), 7)[:n].astype(np.float64)
+    elif kind == 2:  # sparse spikes on a constant
+        v = np.full(n, 42.0); v[rng.integers(0, n, max(n // 20, 1))] = rng.uniform(1, 1e4)
+    elif kind == 3:  # quantised sine (2 decimals)
+        v = np.round(100 + 30 * np.sin(t / rng.uniform(2, 40)), 2)
+    elif kind == 4:  # mixed sign
+        v = rng.normal(0, 100, n)
+    elif kind == 5:  # tiny magnitudes
+        v = rng.uniform(1e-9, 1e-6, n)
+    elif kind == 6:  # huge magnitudes
+        v = rng.uniform(1e12, 1e15, n)
+    elif kind == 7:  # small integers (u8)
+        v = rng.integers(0, 4, n).astype(np.float64) + 1
+    elif kind == 8:  # i16 integers with trend
+        v = np.floor(1000 + 3 * t + rng.normal(0, 2, n))
+    elif kind == 9:  # i32 integers
+        v = np.floor(rng.uniform(1e5, 2e9, n))
+    elif kind == 10:  # exact multi-tone (few FFT bins)
+        v = 1000 + 100 * np.cos(2 * np.pi * 3 * t / max(n, 2)) + 50 * np.sin(2 * np.pi * 7 * t / max(n, 2))
+    else:  # saw tooth with occasional zeros
+        v = (t % 17) * 3.0
+    return np.asarray(v, dtype=np.float64)
+
+
+@pytest.mark.parametrize("seed,e", [(1, 5), (2, 1), (3, 0), (4, 3), (5, 10), (6, 50)])
+def test_fuzz_auto(ctx, A, oracle, seed, e):
+    rng = np.random.default_rng(seed)
+    xs, offs = [], [0]
+    for _ in range(150):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, rng.integers(600, 4097)],
+                           p=[0.15, 0.45, 0.15, 0.05, 0.05, 0.15]))
+        xs.append(_fuzz_frame(rng, n))
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    me = float(np.float32(e) / np.float32(100))
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, me)
+    _log(P.assert_summary(s, 150, "fuzz seed %d e=%d codecs %s" % (seed, e, s["codecs"])))
+    out = ctx.decompress_host(s["records"])
+    ref = oracle.decompress_data(A.bro_prefix(150) + s["records"])
+    assert len(out) == len(ref) == len(x)
+    ch = s["chosen"]
+    for i in range(150):
+        seg = slice(int(offs[i]), int(offs[i + 1]))
+        if ch[i] != oracle.FFT:
+            assert np.array_equal(out[seg], ref[seg], equal_nan=True), (i, ch[i])
