@@ -275,18 +275,100 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     if (mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
         mode = (int)prm.trial_res[fid].chosen;
 
+    // Candidate bookkeeping and pruning exactly as in k_compress (atsc_kernels.hip): the selector keeps
+    // the smallest passing payload, first of [FFT, Polynomial, RLE] on ties, and a ladder's payload
+    // only grows, so a ladder stops once its next payload cannot beat a candidate that already passes.
+    const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
+    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
+    const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
+    const double me = prm.max_err;
+    const bool prune = (mode == ATSC_AUTO) && (0.0 <= me);
+    uint32_t best_size = 0xFFFFFFFFu;
+    int best_owner = 3;
+    auto can_win = [&](uint32_t size_lb, int owner) {
+        return size_lb < best_size || (size_lb == best_size && owner < best_owner);
+    };
+    auto offer = [&](uint32_t size, int owner) {
+        if (can_win(size, owner)) { best_size = size; best_owner = owner; }
+    };
+
+    // ---- RLE (rle.rs:142-189): bound first; exact right away when there are few runs ----
+    uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0, rle_lb = 0xFFFFFFFFu;
+    bool rle_sorted = false, rle_pending = false;
+    auto run_key = [&](uint64_t rec) { return (uint64_t)__double_as_longlong(xs[(uint32_t)rec]); };
+    auto rle_sort_and_group = [&]() {
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += T)
+            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t R = lscan(aux, n, wsum);
+        uint32_t *ends = rhp;
+        for (uint32_t j = tid; j < n; j += T)
+            if (j + 1 >= n || xs[j + 1] != xs[j]) ends[aux[j]] = j;
+        __syncthreads();
+        for (uint32_t r = tid; r < R; r += T) {
+            const uint32_t st = r ? ends[r - 1] + 1 : 0;
+            rrec[r] = ((uint64_t)st << 32) | ends[r];
+        }
+        __syncthreads();
+        uint32_t p2 = 1;
+        while (p2 < R) p2 <<= 1;
+        sort_runs_g(rrec, xs, R, p2);
+        for (uint32_t i = tid; i < R; i += T)
+            aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t D = lscan(aux, R, wsum);
+        for (uint32_t i = tid; i < R; i += T)
+            if (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) rhp[aux[i]] = i;
+        if (tid == 0) rhp[D] = R;
+        __syncthreads();
+        uint32_t hb = 0;
+        for (uint32_t gi = tid; gi < D; gi += T) {
+            const uint32_t h0 = rhp[gi], h1 = rhp[gi + 1];
+            const uint32_t b = value_bytes(bitdepth, xs[(uint32_t)rrec[h0]]) + vlen(h1 - h0);
+            rph[gi] = b;
+            hb += b;
+        }
+        __syncthreads();
+        hb = block_sum_u32<W>(hb, red, parity);
+        rle_R = R;
+        rle_D = D;
+        rle_size = 2 + vlen(D) + hb + rle_ib;
+        rle_sorted = true;
+    };
+    if (run_rle) {
+        uint32_t rcnt = 0, ibs = 0;
+        for (uint32_t j = tid; j < n; j += T)
+            if (j == 0 || xs[j] != xs[j - 1]) { ++rcnt; ibs += vlen(j); }
+        rle_R = block_sum_u32<W>(rcnt, red, parity);
+        rle_ib = block_sum_u32<W>(ibs, red, parity);
+        const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
+        rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * (minval + 1);
+        if (mode == ATSC_RLE || rle_R <= 1024) {
+            rle_sort_and_group();  // its arrays live in their own workspace regions (aux excepted)
+            if (prune) offer(rle_size, 2);
+        } else {
+            rle_pending = true;
+        }
+    }
+
     // =========================================================================================
     // FFT candidate (fft.rs:288-362)
     // =========================================================================================
-    const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
     uint32_t fft_k = 0, fft_size = 0xFFFFFFFFu, fft_trips = 0;
     double fft_err = 0.0;
+    bool fft_done = false;
     const float mxf = (float)smax, mnf = (float)smin;
     if (run_fft) {
         if (mxf == mnf) {
             fft_k = 0;
             fft_size = 1 + 1 + 8;
+            fft_done = true;
+        } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
+            // a single stored bin already loses to a payload that passes
         } else {
+            rle_sorted = false;  // aux (group ids) is reused below; the emitter sorts again if RLE wins
+            bool fft_pruned = false;
             // ---- forward transform of the padded f32 signal ----
             float2 *spec;
             if (P.half) {
@@ -412,8 +494,9 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             uint32_t used = 0, jump = 0;
             double cur = prm.max_err + 1.0;
             while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
-                ++fft_trips;
                 const uint32_t K = min(min(P.mf + jump, Z), nkeys);
+                if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
+                ++fft_trips;
                 // admit bins used..K-1 (fft.rs:401-422: bins 0 and L/2 are purely real for the
                 // real output; an imaginary rounding residue there cannot reach idata[i].re)
                 // `pos as u16` (fft.rs:242): in a 131072-sample frame bins >= 65536 are stored -- and
@@ -493,8 +576,10 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             for (uint32_t i = tid; i < used; i += T) big += ((sel[i].pos & 0xffffu) >= 251) ? 1u : 0u;
             big = block_sum_u32<W>(big, red, parity);
             fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
+            fft_done = !fft_pruned;
             __syncthreads();
         }
+        if (prune && fft_done && fft_err <= me) offer(fft_size, 0);
         dg.fft_size = fft_size; dg.fft_trips = (uint16_t)fft_trips; dg.fft_k = (uint16_t)fft_k;
         dg.fft_err = fft_err;
     }
@@ -502,9 +587,9 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     // =========================================================================================
     // Polynomial candidate (polynomial.rs:209-277); IDW is not offered for large frames
     // =========================================================================================
-    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
     uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
     double poly_err = 0.0;
+    bool poly_done = false, poly_pruned = false;
     if (run_poly) {
         if (smax == smin) {
             poly_K = 0;
@@ -520,11 +605,13 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             double cur = prm.max_err + 1.0;
             uint32_t jump = 0;
             while (round(cur * 10000.0) > prm.poly_q_hi) {
-                ++poly_trips;
                 const uint32_t pts = base + jump;
                 const uint32_t step = max(n / pts, 1u);
                 const uint32_t cnt = (n + step - 1) / step;
                 const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                // payload of this trip, exactly (F64 / U8 points) or from below (>= 1 byte per varint)
+                if (prune && !can_win(2 + vlen(K) + K * (bitdepth == 0 ? 8u : 1u) + 17, 1)) { poly_pruned = true; break; }
+                ++poly_trips;
                 poly_step = step;
                 poly_K = K;
                 if (step > 1) {
@@ -610,118 +697,59 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             vb = block_sum_u32<W>(vb, red, parity);
         }
         poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
+        poly_done = !poly_pruned;
+        if (prune && poly_done && poly_err <= me) offer(poly_size, 1);
         dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
         dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
     }
 
-    // =========================================================================================
-    // RLE candidate (rle.rs:142-189)
-    // =========================================================================================
-    const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
-    uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0;
-    bool rle_sorted = false;
-    auto run_key = [&](uint64_t rec) { return (uint64_t)__double_as_longlong(xs[(uint32_t)rec]); };
-    auto rle_sort_and_group = [&]() {
-        __syncthreads();
-        for (uint32_t j = tid; j < n; j += T)
-            aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
-        __syncthreads();
-        const uint32_t R = lscan(aux, n, wsum);
-        uint32_t *ends = rhp;
-        for (uint32_t j = tid; j < n; j += T)
-            if (j + 1 >= n || xs[j + 1] != xs[j]) ends[aux[j]] = j;
-        __syncthreads();
-        for (uint32_t r = tid; r < R; r += T) {
-            const uint32_t st = r ? ends[r - 1] + 1 : 0;
-            rrec[r] = ((uint64_t)st << 32) | ends[r];
-        }
-        __syncthreads();
-        uint32_t p2 = 1;
-        while (p2 < R) p2 <<= 1;
-        sort_runs_g(rrec, xs, R, p2);
-        for (uint32_t i = tid; i < R; i += T)
-            aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
-        __syncthreads();
-        const uint32_t D = lscan(aux, R, wsum);
-        for (uint32_t i = tid; i < R; i += T)
-            if (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) rhp[aux[i]] = i;
-        if (tid == 0) rhp[D] = R;
-        __syncthreads();
-        uint32_t hb = 0;
-        for (uint32_t gi = tid; gi < D; gi += T) {
-            const uint32_t h0 = rhp[gi], h1 = rhp[gi + 1];
-            const uint32_t b = value_bytes(bitdepth, xs[(uint32_t)rrec[h0]]) + vlen(h1 - h0);
-            rph[gi] = b;
-            hb += b;
-        }
-        __syncthreads();
-        hb = block_sum_u32<W>(hb, red, parity);
-        rle_R = R;
-        rle_D = D;
-        rle_size = 2 + vlen(D) + hb + rle_ib;
-        rle_sorted = true;
-    };
-    if (run_rle) {
-        const double me = prm.max_err;
-        const bool pf = run_fft && (fft_err <= me), pp = run_poly && (poly_err <= me);
-        uint32_t best_other = 0xFFFFFFFFu;
-        if (pf) best_other = fft_size;
-        if (pp && poly_size < best_other) best_other = poly_size;
-        uint32_t rcnt = 0, ibs = 0;
-        for (uint32_t j = tid; j < n; j += T)
-            if (j == 0 || xs[j] != xs[j - 1]) { ++rcnt; ibs += vlen(j); }
-        const uint32_t R = block_sum_u32<W>(rcnt, red, parity);
-        const uint32_t ib = block_sum_u32<W>(ibs, red, parity);
-        rle_R = R;
-        rle_ib = ib;
-        const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
-        const uint32_t lb = 3 + ib + (R >= 2 ? 2u : 1u) * (minval + 1);
-        if (mode == ATSC_RLE || lb < best_other) {
-            if (R <= 1024 || mode == ATSC_RLE) {
-                rle_sort_and_group();
-            } else {
-                const uint32_t H = 2 * n;
-                __syncthreads();
-                for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
-                for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
-                __syncthreads();
-                uint32_t dnew = 0;
-                for (uint32_t j = tid; j < n; j += T) {
-                    if (j + 1 >= n || xs[j + 1] != xs[j]) {
-                        const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
-                        uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
-                        for (;;) {
-                            const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
-                            if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
-                            if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
-                            h = (h + 1 == H) ? 0 : h + 1;
-                        }
+    // ---- RLE with many runs: exact size (hash of run values) only if its bound can still win ----
+    if (run_rle && rle_pending) {
+        if (!prune || can_win(rle_lb, 2)) {
+            const uint32_t H = 2 * n;
+            __syncthreads();
+            for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
+            for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
+            __syncthreads();
+            uint32_t dnew = 0;
+            for (uint32_t j = tid; j < n; j += T) {
+                if (j + 1 >= n || xs[j + 1] != xs[j]) {
+                    const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
+                    uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
+                        if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
+                        if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
+                        h = (h + 1 == H) ? 0 : h + 1;
                     }
                 }
-                __syncthreads();
-                uint32_t hb = 0;
-                for (uint32_t j = tid; j < n; j += T)
-                    if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
-                rle_D = block_sum_u32<W>(dnew, red, parity);
-                hb = block_sum_u32<W>(hb, red, parity);
-                rle_size = 2 + vlen(rle_D) + hb + ib;
             }
+            __syncthreads();
+            uint32_t hb = 0;
+            for (uint32_t j = tid; j < n; j += T)
+                if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
+            rle_D = block_sum_u32<W>(dnew, red, parity);
+            hb = block_sum_u32<W>(hb, red, parity);
+            rle_size = 2 + vlen(rle_D) + hb + rle_ib;
+            if (prune) offer(rle_size, 2);
         } else {
-            rle_size = lb;
+            rle_size = rle_lb;
         }
-        dg.rle_size = (mode == ATSC_RLE || lb < best_other) ? rle_size : 0xFFFFFFFEu;
     }
+    dg.rle_size = rle_size;
 
     // ---- selection (frame/mod.rs:113-147) ----
     int chosen;
     double chosen_err;
     if (mode == ATSC_AUTO) {
-        const double me = prm.max_err;
-        const bool pf = fft_err <= me, pp = poly_err <= me;
-        chosen = ATSC_RLE;
-        uint32_t bs = rle_size;
-        if (pp && poly_size <= bs) { chosen = ATSC_POLYNOMIAL; bs = poly_size; }
-        if (pf && fft_size <= bs) { chosen = ATSC_FFT; bs = fft_size; }
+        if (prune) {
+            chosen = best_owner == 0 ? ATSC_FFT : best_owner == 1 ? ATSC_POLYNOMIAL : ATSC_RLE;
+        } else {  // max_error < 0 or NaN: nothing passes, smallest of all (frame/mod.rs:128-135)
+            chosen = ATSC_FFT;
+            uint32_t bs = fft_size;
+            if (poly_size < bs) { chosen = ATSC_POLYNOMIAL; bs = poly_size; }
+            if (rle_size < bs) { chosen = ATSC_RLE; bs = rle_size; }
+        }
         chosen_err = chosen == ATSC_FFT ? fft_err : chosen == ATSC_POLYNOMIAL ? poly_err : 0.0;
     } else {
         chosen = mode;
