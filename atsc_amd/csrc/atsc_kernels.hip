@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
                 const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
                 double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
+            const double inv_n = 1.0 / (double)n;
                 double cur = prm.max_err + 1.0;
                 uint32_t jump = 0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                             }
                         }
                         s = block_sum_f64<W>(s, red, parity);
-                        cur = s / (double)n;
+                        cur = s * inv_n;
                     } else if (step > 1) {
                         // keys: T(k) = k*step, T(K-1) = n-1.  Catmull-Rom on segments 1..K-3, linear on
                         // the first and the last one (polynomial.rs:349-353).  Everything that is the
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                             }
                         }
                         s = block_sum_f64<W>(s, red, parity);
-                        cur = s / (double)n;
+                        cur = s * inv_n;
                     }
                     if (poly_trips <= 17) jump += dj1;
                     else if (poly_trips <= 22) jump += dj2;
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             // W > 1: one sort of 64-bit keys up front.
             constexpr int KPL = (SPL * 32 + 1 + 63) / 64;
             uint32_t nb[KPL];
+            float bre[KPL], bim[KPL];  // W == 1: the lane's bins, so an admitted bin is one v_readlane away
             uint64_t *keys = (uint64_t *)(spec == A ? B : A);
             uint32_t nz = 0;
             if (W == 1) {
@@ -686,8 +688,12 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 for (int m = 0; m < KPL; ++m) {
                     const uint32_t k = tid + 64 * m;
                     nb[m] = 0;
+                    bre[m] = 0.0f;
+                    bim[m] = 0.0f;
                     if (k < bins) {
                         const float2 z = spec[k];
+                        bre[m] = z.x;
+                        bim[m] = z.y;
                         nb[m] = __float_as_uint(
                             (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
                         nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
@@ -725,6 +731,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 ++fft_trips;
                 for (; used < K; ++used) {
                     uint32_t pos;
+                    float2 z;
                     if (W == 1) {
                         uint32_t lm = nb[0];
 #pragma unroll
@@ -735,13 +742,18 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                         for (int m = KPL - 1; m >= 0; --m)
                             if (nb[m] == wm) cand = tid + 64 * m;
                         pos = wave_min_u32(cand);
+                        float zr = 0.0f, zi = 0.0f;
 #pragma unroll
-                        for (int m = 0; m < KPL; ++m)
+                        for (int m = 0; m < KPL; ++m) {
                             if (tid + 64 * m == pos) nb[m] = 0;
+                            if ((pos >> 6) == (uint32_t)m) { zr = bre[m]; zi = bim[m]; }  // uniform select
+                        }
+                        z = make_float2(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zr), pos & 63)),
+                                        __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zi), pos & 63)));
                     } else {
                         pos = (uint32_t)(keys[used] & 0xffffffffu);
+                        z = spec[pos];
                     }
-                    const float2 z = spec[pos];
                     if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
                     big += (pos >= 251) ? 1u : 0u;
                     // fft.rs:401-422 mirror: bin 0 and (for even L) bin L/2 contribute once;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                     }
                 }
                 s = block_sum_f64<W>(s, red, parity);
-                cur = s / Ld;
+                cur = s * invL;  // mean over the L padded samples (utils/error.rs:115); 1/L rounded once
                 if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
                 else if (fft_trips <= 22) jump += P.dk2;
                 else break;
@@ -1029,9 +1041,10 @@ __global__ __launch_bounds__(256) void k_pack_scan2(uint64_t *__restrict__ block
     if (threadIdx.x == 0) blocksum[nb] = carry;
 }
 
-// one wavefront per frame: header varints + payload copy; also the user-visible side arrays.
-// FUSED: blocksum[] still holds the per-chunk totals (k_pack_scan2 was skipped, at most 64 chunks);
-// every wavefront adds up the totals of the chunks before its own.
+// 16 lanes per frame (4 frames per wavefront, 16 per workgroup): header varints + payload copy; also
+// the user-visible side arrays.  FUSED: blocksum[] still holds the per-chunk totals (k_pack_scan2 was
+// skipped, at most 64 chunks); every wavefront adds up the totals of the chunks before its own (a
+// workgroup never straddles a chunk: PACK_CHUNK is a multiple of 16).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_pack_emit(
     const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
@@ -1039,12 +1052,9 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     const uint8_t *__restrict__ slots, uint8_t *__restrict__ body, uint64_t body_cap,
     uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen, double *__restrict__ err)
 {
-    const uint64_t f = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (f >= n_frames) return;
-    const DevFrame fr = frames[f];
-    const DevResult r = res[f];
-    const uint32_t chunk = (uint32_t)(f / PACK_CHUNK);
+    const uint64_t f = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const uint32_t lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
+    const uint32_t chunk = (uint32_t)(((uint64_t)blockIdx.x * 16) / PACK_CHUNK);
     uint64_t base;
     if (FUSED) {
         const uint64_t v = lane < chunk ? blocksum[lane] : 0;
@@ -1054,9 +1064,12 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     } else {
         base = blocksum[chunk];
     }
+    if (f >= n_frames) return;
+    const DevFrame fr = frames[f];
+    const DevResult r = res[f];
     const uint64_t off = base + local[f];
     const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
-    if (lane == 0) {
+    if (l16 == 0) {
         rec_off[f] = off;
         if (chosen) chosen[f] = (uint8_t)r.chosen;
         if (err) err[f] = r.err;
@@ -1064,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     }
     if (off + hl + r.len > body_cap) return;  // caller sized d_body too small; rec_off tells
     uint8_t *dst = body + off;
-    if (lane == 0) {
+    if (l16 == 0) {
         uint8_t *p = dst;
         *p++ = 41;  // frame_size: size_of_val sum, always 41 on 64-bit (frame/mod.rs:50-56)
         p += put_varint(p, fr.n);
@@ -1072,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
         p += put_varint(p, r.len);
     }
     const uint8_t *src = slots + fr.slot_off;
-    for (uint32_t b = lane; b < r.len; b += 64) dst[hl + b] = src[b];
+    for (uint32_t b = l16; b < r.len; b += 16) dst[hl + b] = src[b];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1131,7 +1144,7 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
-    const dim3 eg((uint32_t)((n_frames + 3) / 4));
+    const dim3 eg((uint32_t)((n_frames + 15) / 16));
     if (nb <= 64) {
         hipLaunchKernelGGL(k_pack_emit<true>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
                            slots, body, body_cap, rec_off, chosen, err);
