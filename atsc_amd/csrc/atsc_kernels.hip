@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
                 const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
                 double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
             const double inv_n = 1.0 / (double)n;
+            const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
                 double cur = prm.max_err + 1.0;
                 uint32_t jump = 0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
@@ -719,6 +720,9 @@ __global__ __launch_bounds__(64 * W) void k_compress(
             float dc = 0.0f;
             const double mxd = (double)mxf, mnd = (double)mnf;
             const double Ld = (double)L;
+            // min/max far from f32 overflow: no NaN can come out of the transform, so the clamp is a plain
+            // min(max()) (a NaN sample still poisons the sum through o - g); otherwise compare-select
+            const bool fast_clamp = fabsf(mxf) < 1e30f && fabsf(mnf) < 1e30f;
             const double invL = 1.0 / Ld;
             const uint32_t magicL = P.magicL;
             uint32_t used = 0, jump = 0, big = 0;
@@ -783,10 +787,16 @@ __global__ __launch_bounds__(64 * W) void k_compress(
 #pragma unroll
                 for (int m = 0; m < SPL; ++m) {
                     if (tid + m * T < L) {
-                        const double v = (double)(acc[m] + dc);
-                        double o = div1e5(round(v * 100000.0));  // fft.rs:208-218
-                        if (o > mxd) o = mxd;
-                        if (o < mnd) o = mnd;
+                        // fft.rs:208-218.  v is an f32, so v * 1e5 is exact (<= 41 significant bits) and
+                        // round-half-away equals trunc(x + copysign(0.5, x)) (checked over the f32 range)
+                        const double x5 = (double)(acc[m] + dc) * 100000.0;
+                        double o = div1e5(trunc(x5 + copysign(0.5, x5)));
+                        if (fast_clamp) {
+                            o = fmin(fmax(o, mnd), mxd);
+                        } else {
+                            if (o > mxd) o = mxd;
+                            if (o < mnd) o = mnd;
+                        }
                         s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
                     }
                 }
