@@ -182,7 +182,7 @@ static int class_of(uint32_t n, uint32_t L)
 
 // Fills the per-length table entry (see DevPlan) and appends the twiddle table of L if new.
 static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64_t> &tw_by_L,
-                            bool nopad = false)
+                            bool nopad = false, bool dec = false)
 {
     DevPlan p;
     memset(&p, 0, sizeof(p));
@@ -228,12 +228,27 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
     p.ab_half = align16(p.direct ? 8 * p.bins : 8 * p.M + 8);
     p.ab_bytes = std::max(2 * p.ab_half, align16(8 * n + 64));
     uint32_t o = 0;
-    p.o_red = o; o += 384;
-    p.o_xs = o; o += align16(8 * n);
-    p.o_tw = o; o += align16(8 * std::max(p.L, n));  // also hosts two u32[n] arrays for RLE
-    p.o_ab = o; o += p.ab_bytes;
-    p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
-    p.o_aux = o; o += align16(4 * (n + 2));
+    if (dec) {
+        p.o_red = o; o += 384;
+        p.o_xs = o; o += align16(8 * n);
+        p.o_tw = o; o += align16(8 * std::max(p.L, n));
+        p.o_ab = o; o += p.ab_bytes;
+        p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
+        p.o_aux = o; o += align16(4 * (n + 2));
+    } else {
+        // Compressor: the frames in flight per CU are bounded by this footprint (160 KB / lds_bytes),
+        // so nothing is kept that two phases can share.  One-wavefront classes reduce through DPP
+        // and need `red` only for the scan total; `aux` (u32[n+2]) lives in the upper part of the
+        // twiddle region, which holds twiddles only from the forward FFT to the end of its ladder
+        // and the RLE group table u32[n] below `aux` otherwise.
+        const int c = class_of(n, p.L);
+        p.o_red = o; o += (c >= 0 && c <= 2) ? 16 : 384;
+        p.o_xs = o; o += align16(8 * n);
+        p.o_tw = o; o += align16(std::max(8 * p.L, 4 * n + 4 * (n + 2)));
+        p.o_aux = p.o_tw + 4 * n;
+        p.o_ab = o; o += p.ab_bytes;
+        p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
+    }
     p.lds_bytes = o;
     auto it = tw_by_L.find(p.L);
     if (it == tw_by_L.end()) {
@@ -926,7 +941,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         auto it = p->tabs.by_n.find(n);
         uint32_t pi;
         if (it == p->tabs.by_n.end()) {
-            int rc = build_plan_entry(n, p->tabs, tw_by_L);
+            int rc = build_plan_entry(n, p->tabs, tw_by_L, false, true);
             if (rc) { atsc_dplan_destroy(p); return fail(ctx, rc, "dplan_create: plan entry"); }
             pi = p->tabs.by_n[n];
         } else {

@@ -23,6 +23,7 @@
 // f64 spline arithmetic is evaluated exactly as written (Rust never fuses a*b+c).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "atsc_device.h"
 
@@ -168,8 +169,9 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // --------------------------------------------------------------------------------------------
 // the frame kernel
 // --------------------------------------------------------------------------------------------
+// one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs)
 template <int W, int SPL, bool IDW>
-__global__ __launch_bounds__(64 * W) void k_compress(
+__global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void k_compress(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
     const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
@@ -201,13 +203,14 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     Sel *sel = (Sel *)(smem + P.o_sel);
     uint32_t *aux = (uint32_t *)(smem + P.o_aux);
     double *red = (double *)(smem + P.o_red);
-    uint32_t *wsum = (uint32_t *)(red + 32);
+    uint32_t *wsum = (W == 1) ? (uint32_t *)red : (uint32_t *)(red + 32);  // W == 1: `red` is 16 bytes
     int parity = 0;
 
     uint8_t *out = slots + fr.slot_off;
     int mode = prm.mode;
 
-    // ---- load samples + twiddles ----------------------------------------------------------
+    // ---- load samples (the twiddles follow when the FFT candidate starts: until then and after
+    // its ladder their region hosts `aux` and the RLE group table) ----------------------------
     {
         const double *src = samples + fr.sample_off;
         if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
@@ -217,8 +220,6 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         } else {
             for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
         }
-        const float2 *twp = twpool + P.tw_off;
-        for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
     }
     __syncthreads();
 
@@ -365,8 +366,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
     bool rle_early = false;  // the early run arrays in AB are still intact
     uint32_t *rrec_std = (uint32_t *)AB;        // 4n: run records (start << 16 | end), n <= 4096
     uint32_t *rhp_std = rrec_std + n;           // 4n+4: group head positions hp[0..D]
-    uint32_t *rps = (uint32_t *)tw;             // 4n  prefix of index varint bytes (emission only)
-    uint32_t *rph_std = rps + n;                // 4n  group header bytes / their prefix
+    uint32_t *rph_std = (uint32_t *)tw;         // 4n  group header bytes / their prefix (aux = tw + 4n)
     auto run_key = [&](uint32_t rec) { return (uint64_t)__double_as_longlong(xs[rec & 0xffffu]); };
     // Sorts the runs by (value bits, start) = BTreeMap order (rle.rs:146,158-169,180-182) and sizes
     // the groups.  Leaves: rrec sorted, aux[i] = heads before i, rhp[g] = index of the first run of
@@ -649,9 +649,14 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         } else if (prune && !can_win(1 + 1 + 9 + 8, 0)) {
             // even a single stored bin is larger than a payload that already passes
         } else {
-            rle_early = false;  // AB is about to be overwritten
+            rle_early = false;  // AB and the twiddle region (aux) are about to be overwritten
+            {
+                const float2 *twp = twpool + P.tw_off;
+                for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
+            }
             float2 *spec;
             if (P.direct) {
+                __syncthreads();
                 dft_direct<W>(P, xs, A, tw);
                 spec = A;
             } else if (P.half) {
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         out_len = hdr + body + 17;
     } else {  // RLE: rle.rs:40-67
-        // runs are sorted by (value bits, start); aux[i] = heads before i; rhp = hp[]; rph = hb[]
+        // runs are sorted by (value bits, start); rhp = hp[]; rph = hb[]
         uint32_t *rrec = rrec_std, *rhp = rhp_std, *rph = rph_std;
         if (rle_early) {  // sized before the ladders, and no ladder touched AB since
             rrec = (uint32_t *)AB;
@@ -955,23 +960,30 @@ __global__ __launch_bounds__(64 * W) void k_compress(
         }
         const uint32_t R = rle_R, D = rle_D;
         const uint32_t hdr = 2 + vlen(D);
-        for (uint32_t i = tid; i < R; i += T) rps[i] = vlen(rrec[i] >> 16);
+        // one scan for both prefixes: (group heads before i) << 16 | index varint bytes before i
+        // (R <= 4096 heads, 3 * 4096 bytes: neither half overflows)
+        for (uint32_t i = tid; i < R; i += T) {
+            const uint32_t rec = rrec[i];
+            const bool head = (i == 0 || run_key(rec) != run_key(rrec[i - 1]));
+            aux[i] = (head ? 0x10000u : 0u) | vlen(rec >> 16);
+        }
         __syncthreads();
-        block_excl_scan<W>(rps, R, wsum);
+        block_excl_scan<W>(aux, R, wsum);
         const uint32_t hb = block_excl_scan<W>(rph, D, wsum);
         uint32_t ibt = 0;
         for (uint32_t i = tid; i < R; i += T) {
             const uint32_t rec = rrec[i], st = rec >> 16;
             const bool head = (i == 0 || run_key(rec) != run_key(rrec[i - 1]));
-            const uint32_t gi = head ? aux[i] : aux[i] - 1;
+            const uint32_t pk = aux[i], ps = pk & 0xffffu;
+            const uint32_t gi = head ? (pk >> 16) : (pk >> 16) - 1;
             const uint32_t ghb = (gi + 1 < D ? rph[gi + 1] : hb);  // header bytes up to and incl. gi
             if (head) {
-                uint8_t *p = out + hdr + rph[gi] + rps[i];
+                uint8_t *p = out + hdr + rph[gi] + ps;
                 p += put_value(p, bitdepth, xs[rec & 0xffffu]);
                 put_varint(p, rhp[gi + 1] - rhp[gi]);
             }
-            put_varint(out + hdr + ghb + rps[i], st);
-            if (i == R - 1) ibt = rps[i] + vlen(st);
+            put_varint(out + hdr + ghb + ps, st);
+            if (i == R - 1) ibt = ps + vlen(st);
         }
         ibt = block_sum_u32<W>(ibt, red, parity);
         if (tid == 0) {
@@ -1109,6 +1121,7 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
 {
     if (count == 0) return hipSuccess;
     auto kern = k_compress<W, SPL, IDW>;
+    if (const char *pad = getenv("ATSC_DEBUG_LDS_PAD")) lds += (uint32_t)atoi(pad);  // occupancy experiments only
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
