@@ -20,7 +20,8 @@ namespace atsc {
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
                                  const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                  const float2 *twpool, const KParams &prm, uint8_t *slots,
-                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s);
+                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s,
+                                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
@@ -57,6 +58,7 @@ struct atsc_ctx {
     uint64_t diag_n = 0;
     hipStream_t diag_stream = nullptr;
     bool want_diag = false;
+    hipStream_t pack_stream = nullptr;  // created by the first pipelined call
     int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
     // optional timing of the dominant k_compress launch (HIP events on the launch stream)
     bool profiling = false;
@@ -103,6 +105,19 @@ struct atsc_plan {
     unsigned char *d_ws = nullptr;   // workspace of the large-frame kernel
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
+    // atsc_compress_plan_dev_pipelined: a second scratch set (allocated on first use) so that the
+    // packing of batch i (context's pack stream) overlaps the codecs of batch i+1 (caller's stream)
+    struct Scratch {
+        DevResult *d_res = nullptr;
+        uint8_t *d_slots = nullptr;
+        uint32_t *d_local = nullptr;
+        uint64_t *d_blocksum = nullptr;
+    };
+    mutable Scratch alt;
+    mutable int turn = 0;
+    mutable hipEvent_t ev_codec[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr};
+    mutable bool pack_pending[2] = {false, false};
+    uint64_t slots_bytes = 0;
 };
 
 struct atsc_dplan {
@@ -331,6 +346,7 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     if (!ctx) return;
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+    if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
     delete ctx;
 }
 extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
@@ -403,6 +419,15 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     if (p->d_local) (void)hipFree(p->d_local);
     if (p->d_blocksum) (void)hipFree(p->d_blocksum);
     if (p->d_ws) (void)hipFree(p->d_ws);
+    if (p->ev_pack[0] || p->ev_pack[1]) (void)hipDeviceSynchronize();  // packing may still read the scratch
+    if (p->alt.d_res) (void)hipFree(p->alt.d_res);
+    if (p->alt.d_slots) (void)hipFree(p->alt.d_slots);
+    if (p->alt.d_local) (void)hipFree(p->alt.d_local);
+    if (p->alt.d_blocksum) (void)hipFree(p->alt.d_blocksum);
+    for (int k = 0; k < 2; ++k) {
+        if (p->ev_codec[k]) (void)hipEventDestroy(p->ev_codec[k]);
+        if (p->ev_pack[k]) (void)hipEventDestroy(p->ev_pack[k]);
+    }
     delete p;
 }
 
@@ -510,7 +535,8 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
     PCHK(hipMalloc((void **)&p->d_ids, n_frames * sizeof(uint32_t)));
     PCHK(hipMemcpy(p->d_ids, ids.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice));
     PCHK(hipMalloc((void **)&p->d_res, n_frames * sizeof(DevResult)));
-    PCHK(hipMalloc((void **)&p->d_slots, std::max<uint64_t>(slot, 16)));
+    p->slots_bytes = std::max<uint64_t>(slot, 16);
+    PCHK(hipMalloc((void **)&p->d_slots, p->slots_bytes));
     PCHK(hipMalloc((void **)&p->d_local, n_frames * sizeof(uint32_t)));
     PCHK(hipMalloc((void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
     if (p->class_count[CLASS_LARGE]) {
@@ -590,7 +616,8 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
 }
 
 static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, const double *d_samples,
-                      const KParams &prm, DevResult *res, atsc_frame_diag *diag, hipStream_t s)
+                      const KParams &prm, uint8_t *d_slots, DevResult *res, atsc_frame_diag *diag,
+                      hipStream_t s)
 {
     UniArgs nouni;
     memset(&nouni, 0, sizeof(nouni));
@@ -599,21 +626,24 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
         hipError_t e;
         if (c == CLASS_LARGE)
             e = launch_compress_large(t->class_count[c], d_samples, t->d_frames, t->d_ids + t->class_first[c],
-                                      t->tabs.d_plans, t->tabs.d_tw, prm, plan->d_slots, res, diag,
+                                      t->tabs.d_plans, t->tabs.d_tw, prm, d_slots, res, diag,
                                       plan->d_ws, plan->ws_stride, plan->ws_slots, s);
         else
             e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
                                       t->d_ids + t->class_first[c], t->tabs.d_plans, t->tabs.d_tw,
-                                      prm, plan->d_slots, res, diag, nouni, s);
+                                      prm, d_slots, res, diag, nouni, s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress (sub plan)", e);
     }
     return ATSC_OK;
 }
 
-extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
-                                      int compressor, int bounded, float max_error, int sample_level,
-                                      uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
-                                      uint8_t *d_chosen, double *d_err, void *stream)
+// Shared body of atsc_compress_plan_dev (pipelined == false: everything on `stream`, scratch set 0)
+// and atsc_compress_plan_dev_pipelined (codecs on `stream`, packing on the context's pack stream,
+// scratch sets alternate).
+static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
+                         int compressor, int bounded, float max_error, int sample_level,
+                         uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
+                         uint8_t *d_chosen, double *d_err, void *stream, bool pipelined)
 {
     if (!ctx || !plan || !d_samples || !d_body || !d_rec_off) return fail(ctx, ATSC_E_INVALID, "compress: null argument");
     if (sample_level < 0 || sample_level > 6) return fail(ctx, ATSC_E_INVALID, "compress: sample level");
@@ -634,6 +664,60 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
     if (compressor == ATSC_IDW && plan->class_count[CLASS_LARGE])
         return fail(ctx, ATSC_E_UNSUPPORTED, "compress: idw on frames longer than 4096 samples");
     hipStream_t s = (hipStream_t)stream;
+    atsc_plan::Scratch S;
+    S.d_res = plan->d_res; S.d_slots = plan->d_slots; S.d_local = plan->d_local; S.d_blocksum = plan->d_blocksum;
+    hipStream_t ps = s;  // stream of the packing kernels
+    int k = 0;
+    if (pipelined) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (!ctx->pack_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking));
+        if (!plan->alt.d_res) {
+            const uint32_t nb = (uint32_t)((plan->n_frames + 1023) / 1024);
+            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_res, plan->n_frames * sizeof(DevResult)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_slots, plan->slots_bytes));
+            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_local, plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_blocksum, (nb + 1) * sizeof(uint64_t)));
+            for (int i = 0; i < 2; ++i) {
+                // ev_codec rides on the last k_compress dispatch (hipExtLaunchKernel stop event)
+                HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_codec[i], hipEventReleaseToDevice));
+                HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_pack[i], hipEventDisableTiming | hipEventReleaseToDevice));
+            }
+        }
+        k = plan->turn;
+        plan->turn ^= 1;
+        if (k) S = plan->alt;
+        ps = ctx->pack_stream;
+        // The packing that last read this scratch set (two calls ago) has to be done before the
+        // codecs overwrite it.  Waited for on the host: a marker on the codec stream would put a
+        // bubble of several microseconds between consecutive k_compress launches, and the host may
+        // still run two batches ahead of the GPU.
+        if (plan->pack_pending[k]) HIPCHK(ctx, hipEventSynchronize(plan->ev_pack[k]));
+    } else {
+        // a plain call after pipelined ones: set 0 may still be read by the pack stream
+        for (int i = 0; i < 2; ++i)
+            if (plan->pack_pending[i]) {
+                HIPCHK(ctx, hipStreamWaitEvent(s, plan->ev_pack[i], 0));
+                plan->pack_pending[i] = false;
+            }
+    }
+    hipEvent_t codec_done = nullptr;  // already attached to the last codec dispatch, if any
+    auto pack = [&]() -> int {
+        if (pipelined) {
+            if (!codec_done) {
+                HIPCHK(ctx, hipEventRecord(plan->ev_codec[k], s));
+                codec_done = plan->ev_codec[k];
+            }
+            HIPCHK(ctx, hipStreamWaitEvent(ps, codec_done, 0));
+        }
+        hipError_t e = launch_pack(plan->d_frames, S.d_res, plan->n_frames, S.d_local, S.d_blocksum,
+                                   S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err, ps);
+        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
+        if (pipelined) {
+            HIPCHK(ctx, hipEventRecord(plan->ev_pack[k], ps));
+            plan->pack_pending[k] = true;
+        }
+        return ATSC_OK;
+    };
     KParams prm;
     prm.max_err = (double)max_error;  // frame/mod.rs:67,118: `max_error as f64`
     prm.poly_target = std::round(prm.max_err * 1000.0) / 1000.0;  // polynomial.rs:230
@@ -684,7 +768,7 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
         if (t->count) {
             KParams tp = prm;
             tp.trial = 1;
-            int rc = launch_sub(ctx, plan, t, d_samples, tp, t->d_res, nullptr, s);
+            int rc = launch_sub(ctx, plan, t, d_samples, tp, S.d_slots, t->d_res, nullptr, s);
             if (rc) return rc;
             prm.trial_res = t->d_res;
             prm.trial_min_n = t->min_n;
@@ -699,20 +783,22 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
             if (rc) return rc;
             plan->nopad = t;
         }
-        int rc = launch_sub(ctx, plan, plan->nopad, d_samples, prm, plan->d_res, d_diag, s);
+        int rc = launch_sub(ctx, plan, plan->nopad, d_samples, prm, S.d_slots, S.d_res, d_diag, s);
         if (rc) return rc;
-        hipError_t e = launch_pack(plan->d_frames, plan->d_res, plan->n_frames, plan->d_local,
-                                   plan->d_blocksum, plan->d_slots, d_body, body_cap, d_rec_off,
-                                   d_chosen, d_err, s);
-        if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
-        return ATSC_OK;
+        return pack();
     }
-    int dominant = 0;
+    int dominant = 0, last_c = 0;
     for (int c = 1; c < N_CLASSES; ++c)
         if (plan->class_count[c] > plan->class_count[dominant]) dominant = c;
+    for (int c = 0; c < N_CLASSES; ++c)
+        if (plan->class_count[c]) last_c = c;
     for (int c = 0; c < N_CLASSES; ++c) {
         if (!plan->class_count[c]) continue;
         const bool timed = ctx->profiling && c == dominant;
+        // the small-frame classes hand the event pair to the dispatch (hipExtLaunchKernel); the
+        // large tier is several launches and is bracketed by recorded events
+        const bool bracket = timed && c == CLASS_LARGE;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (timed) {
             if (ctx->ev_used == ctx->ev_pool.size()) {
                 hipEvent_t a, b;
@@ -720,29 +806,55 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
                 HIPCHK(ctx, hipEventCreate(&b));
                 ctx->ev_pool.emplace_back(a, b);
             }
-            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].first, s));
+            ev0 = ctx->ev_pool[ctx->ev_used].first;
+            ev1 = ctx->ev_pool[ctx->ev_used].second;
+            if (bracket) HIPCHK(ctx, hipEventRecord(ev0, s));
+        }
+        if (pipelined && c == last_c && c != CLASS_LARGE) {
+            // the packing waits for this dispatch's own completion event: no marker on the codec stream
+            if (!ev1) ev1 = plan->ev_codec[k];
+            codec_done = ev1;
         }
         hipError_t e;
         if (c == CLASS_LARGE)
             e = launch_compress_large(plan->class_count[c], d_samples, plan->d_frames,
                                       plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
-                                      plan->tabs.d_tw, prm, plan->d_slots, plan->d_res, d_diag, plan->d_ws,
+                                      plan->tabs.d_tw, prm, S.d_slots, S.d_res, d_diag, plan->d_ws,
                                       plan->ws_stride, plan->ws_slots, s);
         else
             e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
                                       plan->d_frames, plan->d_ids + plan->class_first[c],
-                                      plan->tabs.d_plans, plan->tabs.d_tw, prm, plan->d_slots,
-                                      plan->d_res, d_diag, plan->class_uni[c], s);
+                                      plan->tabs.d_plans, plan->tabs.d_tw, prm, S.d_slots,
+                                      S.d_res, d_diag, plan->class_uni[c], s, ev0, ev1);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
-        if (timed) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ctx->ev_used].second, s));
-            ctx->ev_used++;
-        }
+        if (bracket) HIPCHK(ctx, hipEventRecord(ev1, s));
+        if (timed) ctx->ev_used++;
     }
-    hipError_t e = launch_pack(plan->d_frames, plan->d_res, plan->n_frames, plan->d_local,
-                               plan->d_blocksum, plan->d_slots, d_body, body_cap, d_rec_off,
-                               d_chosen, d_err, s);
-    if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
+    return pack();
+}
+
+extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
+                                      int compressor, int bounded, float max_error, int sample_level,
+                                      uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
+                                      uint8_t *d_chosen, double *d_err, void *stream)
+{
+    return compress_impl(ctx, plan, d_samples, compressor, bounded, max_error, sample_level, d_body,
+                         body_cap, d_rec_off, d_chosen, d_err, stream, false);
+}
+extern "C" int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan,
+                                                const double *d_samples, int compressor, int bounded,
+                                                float max_error, int sample_level, uint8_t *d_body,
+                                                uint64_t body_cap, uint64_t *d_rec_off,
+                                                uint8_t *d_chosen, double *d_err, void *stream)
+{
+    return compress_impl(ctx, plan, d_samples, compressor, bounded, max_error, sample_level, d_body,
+                         body_cap, d_rec_off, d_chosen, d_err, stream, true);
+}
+extern "C" int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream)
+{
+    if (!ctx || !plan) return fail(ctx, ATSC_E_INVALID, "plan_join: null argument");
+    for (int i = 0; i < 2; ++i)
+        if (plan->pack_pending[i]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, plan->ev_pack[i], 0));
     return ATSC_OK;
 }
 

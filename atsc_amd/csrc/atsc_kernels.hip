@@ -22,6 +22,7 @@
 // No MFMA: there is no dense contraction on this path.  Built with -ffp-contract=off so the
 // f64 spline arithmetic is evaluated exactly as written (Rust never fuses a*b+c).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1117,7 +1118,8 @@ template <int W, int SPL, bool IDW>
 static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
-                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
+                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s,
+                               hipEvent_t ev0, hipEvent_t ev1)
 {
     if (count == 0) return hipSuccess;
     auto kern = k_compress<W, SPL, IDW>;
@@ -1127,8 +1129,10 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, samples, frames, ids, plans, twpool,
-                       prm, slots, res, diag, uni);
+    // ev0 / ev1 (optional) take the start / end timestamps of this dispatch itself: no separate
+    // event packets, hence no bubbles around the kernel when it is being timed
+    hipExtLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, ev0, ev1, 0, samples, frames, ids,
+                          plans, twpool, prm, slots, res, diag, uni);
     return hipGetLastError();
 }
 
@@ -1136,25 +1140,27 @@ template <int W, int SPL>
 static hipError_t launch_class(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
-                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
+                               DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s,
+                               hipEvent_t ev0, hipEvent_t ev1)
 {
     if (prm.mode == ATSC_IDW)
-        return launch_class2<W, SPL, true>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    return launch_class2<W, SPL, false>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+        return launch_class2<W, SPL, true>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    return launch_class2<W, SPL, false>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
 }
 
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,
                                  const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                  const float2 *twpool, const KParams &prm, uint8_t *slots,
-                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s)
+                                 DevResult *res, atsc_frame_diag *diag, const UniArgs &uni, hipStream_t s,
+                                 hipEvent_t ev0, hipEvent_t ev1)
 {
     switch (cls) {
-    case 0: return launch_class<1, 2>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
-    case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s);
+    case 0: return launch_class<1, 2>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     default: return hipErrorInvalidValue;
     }
 }

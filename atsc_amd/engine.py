@@ -124,17 +124,24 @@ class Plan:
         }
 
     def compress(self, d_samples, outs, compressor=capi.AUTO, bounded=True, max_error=0.03, level=0,
-                 stream=0):
-        """Enqueues the compression of every frame on `stream` (a raw hipStream_t or 0)."""
+                 stream=0, pipelined=False):
+        """Enqueues the compression of every frame on `stream` (a raw hipStream_t or 0).
+        pipelined=True: atsc_compress_plan_dev_pipelined -- the record packing runs on the context's
+        own stream and overlaps the next call's codecs; `join(stream)` orders a stream after it."""
         assert d_samples.dtype.is_floating_point and d_samples.element_size() == 8
         assert d_samples.is_contiguous() and d_samples.numel() >= self.n_samples
-        rc = capi.lib().atsc_compress_plan_dev(
+        fn = capi.lib().atsc_compress_plan_dev_pipelined if pipelined else capi.lib().atsc_compress_plan_dev
+        rc = fn(
             self.ctx._h, self._h, C.c_void_p(d_samples.data_ptr()), int(compressor),
             int(bool(bounded)), C.c_float(np.float32(max_error)), int(level),
             C.c_void_p(outs["body"].data_ptr()), outs["body"].numel(),
             C.c_void_p(outs["rec_off"].data_ptr()), C.c_void_p(outs["chosen"].data_ptr()),
             C.c_void_p(outs["err"].data_ptr()), C.c_void_p(stream))
         capi.check(rc, self.ctx._h)
+
+    def join(self, stream=0):
+        """`stream` waits on the device for every pipelined packing enqueued so far."""
+        capi.check(capi.lib().atsc_plan_join(self.ctx._h, self._h, C.c_void_p(stream)), self.ctx._h)
 
 
 class DPlan:

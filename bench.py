@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
+                         "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
     args = ap.parse_args()
 
     import torch
@@ -111,20 +114,32 @@ def main():
 
     from atsc_amd import parallel
 
-    # N > 1: two output sets so that the gather of step i overlaps the compression of step i+1
-    outs2 = [outs, plan.alloc_outputs(torch, dev)] if world > 1 else [outs]
+    # Steady state of a compression service: batch after batch.  Two output sets; the record packing
+    # of step i runs on the context's pack stream and overlaps the frame codecs of step i+1 (and, for
+    # N > 1, so does the gather of step i, issued from a side stream that waits for that packing).
+    pipelined = not args.no_pipeline
+    outs2 = [outs, plan.alloc_outputs(torch, dev)]
     pg = None
+    gstream = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def step(i):
-        o = outs2[i % len(outs2)]
+        o = outs2[i % 2]
         if pg is not None:
             pg.before_produce(i % 2)
-        plan.compress(d_x, o, atsc_amd.AUTO, True, me, 0, stream)
+        plan.compress(d_x, o, atsc_amd.AUTO, True, me, 0, stream, pipelined=pipelined)
         if world > 1:
             # the path's only exchange: the encoded records go to rank 0
             if pg is not None:
-                pg.submit(i % 2, o["body"], o["rec_off"][-1:])
-            elif share:  # rehearsal on one GPU: gloo moves host tensors
+                if pipelined:
+                    plan.join(gstream.cuda_stream)
+                    with torch.cuda.stream(gstream):
+                        pg.submit(i % 2, o["body"], o["rec_off"][-1:])
+                else:
+                    pg.submit(i % 2, o["body"], o["rec_off"][-1:])
+                return
+            if pipelined:
+                plan.join(stream)
+            if share:  # rehearsal on one GPU: gloo moves host tensors
                 nb = int(o["rec_off"][-1].item())
                 parallel.gather_records(dist, torch, o["body"][:nb].cpu(), nb, rank, world)
             else:
@@ -158,16 +173,18 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if pipelined:
+        plan.join(stream)
     if pg is not None:
         pg.drain()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()  # device-wide: codec, pack and communicator streams
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if pg is not None and rank == 0:
         segs, sizes = pg.result((args.steps - 1) % 2)
-        assert len(segs) == world and sizes[0] == int(outs2[(args.steps - 1) % len(outs2)]["rec_off"][-1].item())
+        assert len(segs) == world and sizes[0] == int(outs2[(args.steps - 1) % 2]["rec_off"][-1].item())
     kern_ms, launches = ctx.profile_read()
     ctx.set_profiling(False)
     if world > 1:
@@ -224,6 +241,8 @@ def main():
                 "encoded_bytes_rank0": body_bytes,
                 "parallelism": "frames sharded by rank (%d), RCCL gather of records to rank 0" % world
                                if world > 1 else "single GPU",
+                "pipeline": "record packing of step i on the pack stream overlaps the codecs of step i+1 "
+                            "(two scratch + output sets)" if pipelined else "single stream",
             },
             "roofline": {
                 "bound": "hbm",

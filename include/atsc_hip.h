@@ -115,6 +115,24 @@ int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d
                            uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
                            uint8_t *d_chosen, double *d_err, void *stream);
 
+/* The same call for back-to-back batches (a compression service's steady state; main.rs:146-163
+ * run over file after file): the frame codecs are enqueued on `stream`, the packing of the records
+ * into d_body on a stream owned by the context, with two scratch sets inside the plan, so that
+ * packing batch i overlaps the codecs of batch i+1.  A call may block the host until the packing
+ * enqueued two calls earlier has finished (its scratch set is reused); nothing else is
+ * synchronised.  The outputs of a call are complete once a
+ * stream has passed an atsc_plan_join enqueued after it (or after hipDeviceSynchronize); give
+ * consecutive calls their own output buffers if batch i is still being read while batch i+1 is
+ * packed.  atsc_compress_plan_dev may be mixed in; it orders itself after the pending packing. */
+int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
+                                     int compressor, int bounded, float max_error,
+                                     int sample_level, uint8_t *d_body, uint64_t body_cap,
+                                     uint64_t *d_rec_off, uint8_t *d_chosen, double *d_err,
+                                     void *stream);
+/* Makes `stream` wait (device side, no host block) for every packing enqueued so far by
+ * atsc_compress_plan_dev_pipelined on `plan`. */
+int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream);
+
 /* Per-frame diagnostics of the last atsc_compress_plan_dev on this ctx (host copy,
  * synchronises the stream).  One record per frame; used by the parity tests. */
 typedef struct {

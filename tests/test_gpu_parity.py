@@ -523,3 +523,47 @@ def test_fuzz_auto(ctx, A, oracle, seed, e):
         seg = slice(int(offs[i]), int(offs[i + 1]))
         if ch[i] != oracle.FFT:
             assert np.array_equal(out[seg], ref[seg], equal_nan=True), (i, ch[i])
+
+
+# ---------------------------------------------------------------------------------------
+# pipelined entry point: packing on the context's stream, two scratch sets
+# ---------------------------------------------------------------------------------------
+def test_pipelined_batches_match_plain_calls(ctx, A):
+    """Five different batches pushed back-to-back through atsc_compress_plan_dev_pipelined (with a
+    plain call mixed in) give, batch by batch, the bytes of the single-stream call."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    nf, F = 2048, 256
+    off = H.frame_offsets(nf * F, F)
+    plan = ctx.plan(off)
+    stream = torch.cuda.current_stream().cuda_stream
+    batches = [torch.from_numpy(H.synth_series(100 + b, nf * F)).to(dev) for b in range(5)]
+
+    def fetch(o):
+        total = int(o["rec_off"][-1].item())
+        return (o["body"][:total].cpu().numpy().tobytes(), o["rec_off"].cpu().numpy().copy(),
+                o["chosen"].cpu().numpy().copy(), o["err"].cpu().numpy().copy())
+
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for d_x in batches:
+        plan.compress(d_x, o, A.AUTO, True, ME5, 0, stream)
+        torch.cuda.synchronize()
+        ref.append(fetch(o))
+    assert len({r[0] for r in ref}) == len(ref)  # the batches really differ
+
+    outs = [plan.alloc_outputs(torch, dev) for _ in batches]
+    for b, d_x in enumerate(batches):
+        if b == 3:  # a plain call in the middle orders itself after the pending packing
+            plan.compress(d_x, outs[b], A.AUTO, True, ME5, 0, stream)
+        else:
+            plan.compress(d_x, outs[b], A.AUTO, True, ME5, 0, stream, pipelined=True)
+    plan.join(stream)
+    torch.cuda.current_stream().synchronize()  # only the caller's stream: join must cover the packing
+    for b in range(len(batches)):
+        got = fetch(outs[b])
+        assert got[0] == ref[b][0], "batch %d bytes differ" % b
+        assert np.array_equal(got[1], ref[b][1]) and np.array_equal(got[2], ref[b][2])
+        assert np.array_equal(got[3], ref[b][3], equal_nan=True)
+    plan.close() if hasattr(plan, "close") else None
