@@ -150,6 +150,18 @@ DEVI uint32_t wave_sum_u32(uint32_t v)
     v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive prefix sum across the wavefront: Hillis-Steele inside each row of 16 (row_shr), then the
+// row totals ripple through row_bcast:15 / row_bcast:31 -- six v_add_u32_dpp, no LDS crossbar
+DEVI uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_u32<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_u32<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_u32<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_u32<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
 DEVI uint32_t wave_max_u32(uint32_t v)
 {
     v = max(v, dpp_u32<0xb1, 0xf>(v));
@@ -309,16 +321,18 @@ DEVI uint32_t block_excl_scan(uint32_t *arr, uint32_t count, uint32_t *wsum)
 {
     constexpr int T = 64 * W;
     const int tid = threadIdx.x;
+    if (W == 1 && count <= 64) {  // one entry per lane: the payload emitters and the few-runs RLE
+        const uint32_t v = (uint32_t)tid < count ? arr[tid] : 0u;
+        const uint32_t in = wave_incl_scan_u32(v);
+        if ((uint32_t)tid < count) arr[tid] = in - v;
+        __syncthreads();
+        return (uint32_t)__builtin_amdgcn_readlane((int)in, 63);
+    }
     const uint32_t C = (count + T - 1) / T;
     const uint32_t b = min((uint32_t)tid * C, count), e = min(b + C, count);
     uint32_t s = 0;
     for (uint32_t i = b; i < e; ++i) s += arr[i];
-    uint32_t incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += t;
-    }
+    uint32_t incl = wave_incl_scan_u32(s);
     if (W > 1) {
         if ((tid & 63) == 63) wsum[tid >> 6] = incl;
         __syncthreads();
@@ -422,6 +436,22 @@ DEVI double div1e5(double r)
     const double q = r * y;
     const double rem = fma(-q, 100000.0, r);
     return fma(rem, y, q);
+}
+
+// 1 / |g| for the MAPE weights (utils/error.rs:104-116 divides by |g|; the product form is within
+// an ulp of it).  v_rcp_f64 + two Newton steps instead of the ~30-instruction IEEE divide, for
+// magnitudes where neither the seed nor the residuals leave the normal range; zero (-> inf),
+// subnormal, huge, inf and NaN inputs take the divide.
+DEVI double recip_abs(double g)
+{
+    const double a = fabs(g);
+    if (a > 1e-290 && a < 1e290) {
+        double r = __builtin_amdgcn_rcp(a);
+        r = fma(fma(-a, r, 1.0), r, r);
+        r = fma(fma(-a, r, 1.0), r, r);
+        return r;
+    }
+    return 1.0 / a;
 }
 
 struct Sel {

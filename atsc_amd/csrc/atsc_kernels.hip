@@ -437,6 +437,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
+    if (prm.debug_stop == 10) return;
     // A payload below 19 bytes (FFT with one bin; Polynomial needs at least 23) already beats both
     // ladders: skip loading their operands.
     if (!(prune && best_size < 19)) {
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 int32_t i = (int32_t)j - (int32_t)pre;
                 i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
                 g[m] = xs[i];
-                inv[m] = 1.0 / fabs(g[m]);
+                inv[m] = recip_abs(g[m]);
             } else {
                 g[m] = 1.0;
                 inv[m] = 0.0;
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
+    if (prm.debug_stop == 11) return;
     // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
     bool poly_first = false;
     if (prune && run_fft && run_poly && smax != smin) {
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     };
 
     if (poly_first) eval_poly();
+    if (prm.debug_stop == 13) return;
     // =========================================================================================
     // FFT candidate: fft.rs:288-362
     // =========================================================================================
@@ -778,32 +781,39 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
 #pragma unroll
                         for (int m = 0; m < SPL; ++m) {
-                            if (tid + m * T < L) {
-                                const float2 w = tw[idx];
-                                acc[m] = fmaf(a, w.x, acc[m]);
-                                acc[m] = fmaf(-b, w.y, acc[m]);
-                            }
+                            // lanes beyond L accumulate too (idx < L always): their acc is never
+                            // looked at, or weighs 0 in the error sum, and no exec masking is needed
+                            const float2 w = tw[idx];
+                            acc[m] = fmaf(a, w.x, acc[m]);
+                            acc[m] = fmaf(-b, w.y, acc[m]);
                             idx += stp;
-                            if (idx >= L) idx -= L;
+                            idx = min(idx, idx - L);  // idx < 2L: unsigned wrap picks the reduced value
                         }
                     }
                 }
                 if (!prm.bounded) { cur = 0.0; break; }
                 double s = 0.0;
+                // fft.rs:208-218.  v is an f32, so v * 1e5 is exact (<= 41 significant bits) and
+                // round-half-away equals trunc(x + copysign(0.5, x)) (checked over the f32 range)
+                if (fast_clamp) {
+                    // every o is finite, and the lanes beyond L carry g = 1, 1/|g| = 0: no guard
 #pragma unroll
-                for (int m = 0; m < SPL; ++m) {
-                    if (tid + m * T < L) {
-                        // fft.rs:208-218.  v is an f32, so v * 1e5 is exact (<= 41 significant bits) and
-                        // round-half-away equals trunc(x + copysign(0.5, x)) (checked over the f32 range)
+                    for (int m = 0; m < SPL; ++m) {
                         const double x5 = (double)(acc[m] + dc) * 100000.0;
                         double o = div1e5(trunc(x5 + copysign(0.5, x5)));
-                        if (fast_clamp) {
-                            o = fmin(fmax(o, mnd), mxd);
-                        } else {
+                        o = fmin(fmax(o, mnd), mxd);
+                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < SPL; ++m) {
+                        if (tid + m * T < L) {
+                            const double x5 = (double)(acc[m] + dc) * 100000.0;
+                            double o = div1e5(trunc(x5 + copysign(0.5, x5)));
                             if (o > mxd) o = mxd;
                             if (o < mnd) o = mnd;
+                            s += fabs(o - g[m]) * inv[m];
                         }
-                        s += fabs(o - g[m]) * inv[m];  // utils/error.rs:104-116
                     }
                 }
                 s = block_sum_f64<W>(s, red, parity);
@@ -824,7 +834,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
 
 
+    if (prm.debug_stop == 14) return;
     if (!poly_first) eval_poly();
+    if (prm.debug_stop == 15) return;
 
     // ---- RLE with many runs: exact size only if its bound can still win ----
     if (run_rle && rle_pending) {

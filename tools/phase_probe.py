@@ -1,4 +1,6 @@
-"""Cumulative phase timing of k_compress through ATSC_DEBUG_STOP (dev aid, GPU box only)."""
+"""Cumulative phase timing of k_compress<1,5> per synthetic class through ATSC_DEBUG_STOP (dev aid,
+GPU box only).  The stops cut the kernel short, so later phases run unpruned by what was skipped:
+read the differences as indications, not as an exact budget."""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -11,22 +13,22 @@ n = 40960*256; me = float(np.float32(5)/np.float32(100)); dev = torch.device("cu
 ctx = atsc_amd.Context(0); off = H.frame_offsets(n, 256); plan = ctx.plan(off); outs = plan.alloc_outputs(torch, dev)
 st = torch.cuda.current_stream().cuda_stream
 res = {}
-for klass in (0, 1, None):
+for klass in (0, 1, 2, 3, None):
     x = H.synth_series(0, n, klass=klass); d_x = torch.from_numpy(x).to(dev)
     for _ in range(2): plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, st)
     torch.cuda.synchronize(); ctx.set_profiling(True)
-    for _ in range(5): plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, st)
+    for _ in range(4): plan.compress(d_x, outs, atsc_amd.AUTO, True, me, 0, st)
     torch.cuda.synchronize(); ms, cnt = ctx.profile_read(); ctx.set_profiling(False)
     res[str(klass)] = round(ms/cnt*1e3, 1)
 print(json.dumps(res))
 ''' % ROOT
-out = {}
-for stop in (1, 2, 3, 4, 5, 6, 7, 8, 0):
+names = [(1, "load+stats"), (3, "+const/noop/trial checks"), (10, "+RLE bound / early sizing"),
+         (11, "+g, 1/|g| registers"), (13, "+poly if first"), (4, "+tw load, fwd FFT"), (5, "+norms, zero cut"),
+         (14, "+FFT ladder"), (15, "+poly if second"), (8, "+pending RLE sizing"), (0, "all (+select, emit)")]
+print("%-28s %s" % ("us per 40960 frames", "class 0 / 1 / 2 / 3 / mixed"))
+for stop, name in names:
     env = dict(os.environ, ATSC_DEBUG_STOP=str(stop))
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    out[stop] = json.loads(line[-1]) if line else r.stderr[-300:]
-names = {1: "load+stats", 2: "+const/noop checks", 3: "+g/inv regs", 4: "+fwd FFT", 5: "+norms/Z",
-         6: "+ladder", 7: "+poly", 8: "+rle", 0: "all (+select/emit)"}
-for k in (1, 2, 3, 4, 5, 6, 7, 8, 0):
-    print("%-22s %s" % (names[k], out[k]))
+    d = json.loads(line[-1]) if line else None
+    print("%-28s %s" % (name, "  ".join("%7.1f" % d[k] for k in ("0", "1", "2", "3", "None")) if d else r.stderr[-300:]), flush=True)
