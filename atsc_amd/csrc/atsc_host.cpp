@@ -313,7 +313,7 @@ extern "C" const char *atsc_strerror(int rc)
     case ATSC_E_INVALID: return "invalid argument";
     case ATSC_E_NOMEM: return "out of memory";
     case ATSC_E_UNSUPPORTED:
-        return "not implemented on the GPU path (idw or decode of frames longer than 4096 samples; frames longer than 131072)";
+        return "not implemented on the GPU path (frames longer than 131072 samples)";
     case ATSC_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case ATSC_E_HIP: return "HIP runtime error";
     case ATSC_E_CAPACITY: return "output buffer too small";
@@ -661,8 +661,6 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     default:
         return fail(ctx, ATSC_E_INVALID, "compress: unknown compressor id");
     }
-    if (compressor == ATSC_IDW && plan->class_count[CLASS_LARGE])
-        return fail(ctx, ATSC_E_UNSUPPORTED, "compress: idw on frames longer than 4096 samples");
     hipStream_t s = (hipStream_t)stream;
     atsc_plan::Scratch S;
     S.d_res = plan->d_res; S.d_slots = plan->d_slots; S.d_local = plan->d_local; S.d_blocksum = plan->d_blocksum;
@@ -1044,10 +1042,6 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         if (nout == 0 || nout > MAX_FRAME) {
             atsc_dplan_destroy(p);
             return fail(ctx, nout == 0 ? ATSC_E_FORMAT : ATSC_E_UNSUPPORTED, "dplan_create: frame sample count");
-        }
-        if (tag == ATSC_IDW && nout > MAX_FRAME_TIER_M) {
-            atsc_dplan_destroy(p);
-            return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: idw frame longer than 4096 samples");
         }
         const uint32_t n = (uint32_t)nout;
         auto it = p->tabs.by_n.find(n);

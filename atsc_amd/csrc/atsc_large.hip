@@ -279,7 +279,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     // the smallest passing payload, first of [FFT, Polynomial, RLE] on ties, and a ladder's payload
     // only grows, so a ladder stops once its next payload cannot beat a candidate that already passes.
     const bool run_fft = (mode == ATSC_AUTO || mode == ATSC_FFT);
-    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL);
+    const bool run_poly = (mode == ATSC_AUTO || mode == ATSC_POLYNOMIAL || mode == ATSC_IDW);
+    const bool idw = (mode == ATSC_IDW);  // forced codec only (polynomial.rs:29-34,202-207)
     const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
     const double me = prm.max_err;
     const bool prune = (mode == ATSC_AUTO) && (0.0 <= me);
@@ -585,7 +586,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
 
     // =========================================================================================
-    // Polynomial candidate (polynomial.rs:209-277); IDW is not offered for large frames
+    // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
+    // interpolation (polynomial.rs:375-393)
     // =========================================================================================
     uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
     double poly_err = 0.0;
@@ -614,7 +616,44 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 ++poly_trips;
                 poly_step = step;
                 poly_K = K;
-                if (step > 1) {
+                if (idw && step > 1) {
+                    // inverse_distance_weight 0.1.1, power 2 (oracle: poly_idw_to_data): a sample that
+                    // sits on a point takes its value, every other sample sums w = 1 / d^2 over ALL K
+                    // points in ascending order.  d is an integer, so the weights come from a per-frame
+                    // table w[d] = 1.0 / (d * d) kept in the (idle) FFT buffer: O(n K) FMAs per trip.
+                    double *wtab = (double *)A;
+                    if (poly_trips == 1) {
+                        for (uint32_t d = tid + 1; d < n; d += T) {
+                            const double dd = (double)d;
+                            wtab[d] = 1.0 / (dd * dd);
+                        }
+                        __syncthreads();
+                    }
+                    double s = 0.0;
+                    for (uint32_t i = tid; i < n; i += T) {
+                        double sv;
+                        const uint32_t q = i / step;
+                        if (i == n - 1 || (q * step == i && q < K - 1)) {
+                            sv = xs[i];
+                        } else {
+                            double num = 0.0, den = 0.0;
+                            for (uint32_t k = 0; k < K; ++k) {
+                                const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                                const double w = wtab[pk > i ? pk - i : i - pk];
+                                num += w * xs[pk];
+                                den += w;
+                            }
+                            sv = num / den;
+                        }
+                        double o = div1e5(round(sv * 100000.0));
+                        if (o < smin) o = smin;
+                        else if (o > smax) o = smax;
+                        const double g = xs[i];
+                        s += fabs((o - g) / g);
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                } else if (step > 1) {
                     const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
                     const uint32_t gapL = (n - 1) - (K - 2) * step;
                     const double stepd = (double)step, gapLd = (double)gapL;
@@ -753,7 +792,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         chosen_err = chosen == ATSC_FFT ? fft_err : chosen == ATSC_POLYNOMIAL ? poly_err : 0.0;
     } else {
         chosen = mode;
-        chosen_err = mode == ATSC_FFT ? fft_err : mode == ATSC_POLYNOMIAL ? poly_err : 0.0;
+        chosen_err = mode == ATSC_FFT ? fft_err : (mode == ATSC_POLYNOMIAL || mode == ATSC_IDW) ? poly_err : 0.0;
     }
 
     uint32_t out_len = 0;
@@ -783,7 +822,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             put_f32(out + hdr + body + 4, mnf);
         }
         out_len = hdr + body + 8;
-    } else if (chosen == ATSC_POLYNOMIAL) {
+    } else if (chosen == ATSC_POLYNOMIAL || chosen == ATSC_IDW) {
         const uint32_t hdr = 2 + vlen(poly_K);
         uint32_t body;
         if (bitdepth == 0 || bitdepth == 3) {
@@ -806,7 +845,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             }
         }
         if (tid == 0) {
-            out[0] = 0;
+            out[0] = idw ? 1 : 0;  // PolynomialType::{Polynomial, Idw}
             out[1] = (uint8_t)bitdepth;
             put_varint(out + 2, poly_K);
             put_f64(out + hdr + body, smin);
@@ -940,7 +979,8 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             const uint32_t id = (uint32_t)rd_varint(r);
             const uint32_t bd = (uint32_t)rd_varint(r);
             const uint64_t cnt = rd_varint(r);
-            if (id != 0 || bd > 3 || cnt > n) r.bad = true;  // idw is not offered for large frames
+            if (id > 1 || bd > 3 || cnt > n) r.bad = true;
+            h.f1 = (float)id;  // 0 Polynomial, 1 Idw
             h.u2 = bd;
             h.u0 = (uint32_t)cnt;
             if (!r.bad) {
@@ -1040,8 +1080,34 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             __syncthreads();
         }
         const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+        const bool idw = (h.f1 != 0.0f);  // polynomial.rs:395-404 picks the interpolation by the id
+        double *wtab = (double *)A;       // w[d] = 1 / d^2, as in k_compress_large
+        if (idw) {
+            for (uint32_t d = tid + 1; d < n; d += T) {
+                const double dd = (double)d;
+                wtab[d] = 1.0 / (dd * dd);
+            }
+            __syncthreads();
+        }
         for (uint32_t j = tid; j < n; j += T) {
-            const double sv = spline_eval([&](uint32_t k) { return vals[k]; }, j, n, step, K, magic);
+            double sv;
+            if (idw) {
+                const uint32_t q = j / step;
+                if (j == n - 1 || (q * step == j && q < K - 1)) {
+                    sv = vals[j == n - 1 ? K - 1 : q];
+                } else {
+                    double num = 0.0, den = 0.0;
+                    for (uint32_t k = 0; k < K; ++k) {
+                        const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                        const double w = wtab[pk > j ? pk - j : j - pk];
+                        num += w * vals[k];
+                        den += w;
+                    }
+                    sv = num / den;
+                }
+            } else {
+                sv = spline_eval([&](uint32_t k) { return vals[k]; }, j, n, step, K, magic);
+            }
             double o = round(sv * 100000.0) / 100000.0;
             if (o < mn) o = mn;
             else if (o > mx) o = mx;

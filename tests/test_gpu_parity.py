@@ -567,3 +567,36 @@ def test_pipelined_batches_match_plain_calls(ctx, A):
         assert np.array_equal(got[1], ref[b][1]) and np.array_equal(got[2], ref[b][2])
         assert np.array_equal(got[3], ref[b][3], equal_nan=True)
     plan.close() if hasattr(plan, "close") else None
+
+
+# ---------------------------------------------------------------------------------------
+# forced Idw on large frames (polynomial.rs:375-393 at 4097 .. 131072 samples)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bounded", [True, False])
+def test_idw_large_frames(ctx, A, oracle, bounded):
+    sizes = [4097, 5000, 8192, 12000, 20000]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in (0, 1, 2, 3):
+            xs.append(H.synth_series(900 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.IDW, bounded, ME5)
+    _log(P.assert_summary(s, len(off) - 1, "idw large frames bounded=%s" % bounded))
+    assert s["tol"] == 0 and s["boundary"] == 0
+    # decode: the oracle's stream through the GPU decoder, bit for bit
+    bro, chosen, _ = oracle.stream_compress(x, off, A.IDW, bounded, ME5, 0)
+    ref = oracle.decompress_data(bro)
+    body_off, _ = A.bro_open(bro)
+    out = ctx.decompress_host(bro[body_off:])
+    assert np.array_equal(out, ref)
+
+
+def test_idw_one_131072_frame(ctx, A, oracle):
+    """The reference chunker's largest frame through forced Idw (O(n K) per ladder trip)."""
+    x = H.synth_series(77, 131072, klass=0)
+    off = np.array([0, len(x)], dtype=np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.IDW, True, ME5)
+    _log(P.assert_summary(s, 1, "idw 131072"))
+    assert s["tol"] == 0 and s["boundary"] == 0
