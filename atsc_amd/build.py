@@ -6,9 +6,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libatsc_hip.so")
-SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp", "atsc_stream.cpp"]
+SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp", "atsc_stream.cpp",
+           "atsc_vsri.cpp"]
 CLI = os.path.join(HERE, "bin", "atsc")
 CLI_SRC = "atsc_cli.cpp"
+CLI2 = os.path.join(HERE, "bin", "csv-compressor")
+CLI2_SRC = "csv_compressor_cli.cpp"
 DEPS = SOURCES + ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
 # -ffp-contract=off: the f64 spline / rounding arithmetic must evaluate exactly as written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -22,10 +25,10 @@ def _hipcc():
 
 
 def stale():
-    if not os.path.exists(LIB) or not os.path.exists(CLI):
+    if not os.path.exists(LIB) or not os.path.exists(CLI) or not os.path.exists(CLI2):
         return True
-    t = min(os.path.getmtime(LIB), os.path.getmtime(CLI))
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS + [CLI_SRC])
+    t = min(os.path.getmtime(LIB), os.path.getmtime(CLI), os.path.getmtime(CLI2))
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS + [CLI_SRC, CLI2_SRC])
 
 
 def build(force=False, verbose=False):
@@ -42,6 +45,12 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cli))
     subprocess.check_call(cli, cwd=CSRC)
+    # the `csv-compressor` front end (csv-compressor/src/main.rs)
+    cli2 = [_hipcc(), "-O2", "-std=c++17", "-o", CLI2, os.path.join(CSRC, CLI2_SRC), "-L" + HERE, "-latsc_hip",
+            "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cli2))
+    subprocess.check_call(cli2, cwd=CSRC)
     return LIB
 
 

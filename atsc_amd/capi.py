@@ -36,6 +36,8 @@ class FrameDiag(C.Structure):
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); must cover every function declared in include/atsc_hip.h
@@ -91,6 +93,30 @@ SIGNATURES = {
     "atsc_next_size": (C.c_uint64, [C.c_uint64]),
     "atsc_bro_prefix": (C.c_uint64, [C.c_uint64, _u8p]),
     "atsc_bro_open": (C.c_int, [_u8p, C.c_uint64, _u64p, _u64p]),
+    # csv-compressor front end (atsc_vsri.cpp)
+    "atsc_vsri_new": (_vp, []),
+    "atsc_vsri_free": (None, [_vp]),
+    "atsc_vsri_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "atsc_vsri_flush_to": (C.c_int, [_vp, C.c_char_p]),
+    "atsc_vsri_update_for_point": (C.c_int, [_vp, C.c_int32]),
+    "atsc_vsri_min": (C.c_int32, [_vp]),
+    "atsc_vsri_max": (C.c_int32, [_vp]),
+    "atsc_vsri_segment_count": (C.c_uint64, [_vp]),
+    "atsc_vsri_segment": (C.c_int, [_vp, C.c_uint64, _i32p]),
+    "atsc_vsri_get_sample_count": (C.c_int32, [_vp]),
+    "atsc_vsri_get_sample": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_get_next_sample": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_get_previous_sample": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_get_this_or_next": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_get_this_or_previous": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_get_time": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "atsc_vsri_is_empty": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "atsc_vsri_get_all_timestamps": (C.c_int, [_vp, C.POINTER(_i32p), _u64p]),
+    "atsc_day_elapsed_seconds": (C.c_int, [C.c_int64, _i32p]),
+    "atsc_samples_csv_read": (C.c_int, [C.c_char_p, C.POINTER(_i64p), C.POINTER(_f64p), _u64p]),
+    "atsc_samples_csv_write": (C.c_int, [C.c_char_p, _i64p, _f64p, C.c_uint64]),
+    "atsc_metric_index_samples": (C.c_int, [_vp, _i64p, C.c_uint64, _u64p]),
+    "atsc_metric_sample_times": (C.c_int, [_vp, C.c_uint64, _i64p]),
 }
 
 _lib = None

@@ -451,6 +451,32 @@ static void split_csv(const std::string &line, std::vector<std::string> &f)
     f.push_back(cur);
 }
 
+// shared with atsc_vsri.cpp (the csv-compressor front end)
+namespace atsc_text {
+bool parse_rust_f64(const std::string &s, double &v) { return ::parse_rust_f64(s, v); }
+void split_csv(const std::string &line, std::vector<std::string> &f) { ::split_csv(line, f); }
+// BufRead::lines / the csv reader's record split: "\n" or "\r\n" ends a line, no empty line after
+// the final terminator
+int read_lines(const char *path, std::vector<std::string> &lines)
+{
+    std::vector<uint8_t> buf;
+    int rc = read_file(path, buf);
+    if (rc) return rc;
+    std::string cur;
+    for (uint8_t c : buf) {
+        if (c == '\n') {
+            if (!cur.empty() && cur.back() == '\r') cur.pop_back();
+            lines.push_back(cur);
+            cur.clear();
+        } else {
+            cur.push_back((char)c);
+        }
+    }
+    if (!cur.empty()) lines.push_back(cur);
+    return ATSC_OK;
+}
+}  // namespace atsc_text
+
 extern "C" int atsc_csv_read(const char *path, int has_header, const char *time_field, const char *value_field,
                              double **out, uint64_t *n)
 {

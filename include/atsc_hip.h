@@ -244,6 +244,46 @@ uint64_t atsc_bro_prefix(uint64_t n_frames, uint8_t *out);
  * the frame count, or ATSC_E_FORMAT / ATSC_E_VERSION. */
 int atsc_bro_open(const uint8_t *bro, uint64_t len, uint64_t *body_off, uint64_t *n_frames);
 
+/* ------------------------------------------------------------------------------------------
+ * csv-compressor front end: host-only, no GPU context needed.
+ * ------------------------------------------------------------------------------------------ */
+/* VSRI, the timestamp index (vsri/src/lib.rs): continuous segments y = m*x + b of equally spaced
+ * points, [m, x0, y0, count] each (lib.rs:100-106).  Arithmetic is Rust's release-mode i32
+ * (wrapping).  Look-ups return 1 = Some(*out), 0 = None, ATSC_E_INVALID where the reference
+ * panics (division by zero on a one-point segment, lib.rs:311). */
+typedef struct atsc_vsri atsc_vsri;
+atsc_vsri *atsc_vsri_new(void);                                      /* Vsri::new, lib.rs:110-119 */
+void atsc_vsri_free(atsc_vsri *v);
+int atsc_vsri_load(const char *path, atsc_vsri **out);               /* Vsri::load, lib.rs:447-486 */
+int atsc_vsri_flush_to(const atsc_vsri *v, const char *path);        /* Vsri::flush_to, lib.rs:424-443 */
+/* Vsri::update_for_point (lib.rs:236-273); ATSC_E_INVALID = Error::UpdateIndexForPointError */
+int atsc_vsri_update_for_point(atsc_vsri *v, int32_t y);
+int32_t atsc_vsri_min(const atsc_vsri *v);                           /* lib.rs:276-278 */
+int32_t atsc_vsri_max(const atsc_vsri *v);                           /* lib.rs:281-283 */
+uint64_t atsc_vsri_segment_count(const atsc_vsri *v);
+int atsc_vsri_segment(const atsc_vsri *v, uint64_t i, int32_t out[4]);
+int32_t atsc_vsri_get_sample_count(const atsc_vsri *v);              /* lib.rs:355-358 */
+int atsc_vsri_get_sample(const atsc_vsri *v, int32_t y, int32_t *out);           /* lib.rs:301-317 */
+int atsc_vsri_get_next_sample(const atsc_vsri *v, int32_t y, int32_t *out);      /* lib.rs:154-169 */
+int atsc_vsri_get_previous_sample(const atsc_vsri *v, int32_t y, int32_t *out);  /* lib.rs:175-193 */
+int atsc_vsri_get_this_or_next(const atsc_vsri *v, int32_t y, int32_t *out);     /* lib.rs:137-141 */
+int atsc_vsri_get_this_or_previous(const atsc_vsri *v, int32_t y, int32_t *out); /* lib.rs:144-148 */
+int atsc_vsri_get_time(const atsc_vsri *v, int32_t x, int32_t *out);             /* lib.rs:320-341 */
+int atsc_vsri_is_empty(const atsc_vsri *v, int32_t t0, int32_t t1);  /* lib.rs:198-232; 1 / 0 */
+int atsc_vsri_get_all_timestamps(const atsc_vsri *v, int32_t **out, uint64_t *n); /* lib.rs:344-353; atsc_free */
+/* vsri::day_elapsed_seconds (lib.rs:49-57); ATSC_E_INVALID outside chrono's DateTime range */
+int atsc_day_elapsed_seconds(int64_t timestamp_sec, int32_t *out);
+/* csv-compressor/src/csv.rs:41-56: `timestamp,value` files (i64, f64; csv crate reader / writer,
+ * ryu float formatting).  Arrays from the reader are released with atsc_free. */
+int atsc_samples_csv_read(const char *path, int64_t **ts, double **val, uint64_t *n);
+int atsc_samples_csv_write(const char *path, const int64_t *ts, const double *val, uint64_t n);
+/* Metric::append_samples (metric.rs:53-65), index side: ts_ms[i] / 1000 -> seconds since midnight
+ * -> update_for_point.  On failure *failed_at (may be NULL) is the offending sample. */
+int atsc_metric_index_samples(atsc_vsri *index, const int64_t *ts_ms, uint64_t n, uint64_t *failed_at);
+/* Metric::get_samples (metric.rs:83-97): out[i] = index.get_time(i); ATSC_E_INVALID where that is
+ * None (an unwrap panic in the reference). */
+int atsc_metric_sample_times(const atsc_vsri *index, uint64_t n, int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

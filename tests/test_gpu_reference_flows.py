@@ -215,3 +215,94 @@ def test_cli_rejects_bad_flags(atsc_bin, tmp_path):
         assert r.returncode == 2
     r = subprocess.run([atsc_bin, str(tmp_path / "missing.wbro")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1  # main.rs:239-242
+
+
+# ---- csv-compressor/src/main.rs --------------------------------------------
+@pytest.fixture(scope="module")
+def csvc_bin(A):
+    p = os.path.join(os.path.dirname(A.__file__), "bin", "csv-compressor")
+    assert os.path.exists(p), "csv-compressor CLI was not built"
+    return p
+
+
+def _metric_csv(path, n=3000, klass=0):
+    """`timestamp,value` file: millisecond timestamps every 15 s from 00:00:30 UTC with one gap."""
+    from oracle import vsri_oracle as VO
+
+    vals = H.synth_series(321, n, klass=klass)
+    day = 1700006400
+    ts, t = [], (day + 30) * 1000
+    for i in range(n):
+        ts.append(t + (i * 37) % 1000)
+        t += 15000 if i != n // 2 else 15000 * 20
+    with open(path, "w") as f:
+        f.write(VO.samples_to_csv_text(ts, vals))
+    return np.array(ts, dtype=np.int64), vals
+
+
+@pytest.mark.parametrize("compressor,error", [("noop", 5), ("constant", 5), ("auto", 0), ("auto", 5),
+                                              ("fft", 5), ("polynomial", 3), ("idw", 3)])
+def test_csv_compressor_round_trip(A, ctx, oracle, csvc_bin, tmp_path, compressor, error):
+    from oracle import vsri_oracle as VO
+
+    src = tmp_path / "metric.csv"
+    ts, vals = _metric_csv(src)
+    _run(csvc_bin, "--output-vsri", "--output-wavbrro", "--compressor", compressor, "-e", error, src)
+    # the three outputs of the compress leg (main.rs:174-207)
+    index = VO.metric_from_samples(ts)
+    assert (tmp_path / "metric.vsri").read_text() == index.to_text()
+    assert (tmp_path / "metric.wavbro").read_bytes() == A.wbro_to_bytes(vals)
+    bro = (tmp_path / "metric.bro").read_bytes()
+    cid = getattr(A, compressor.upper())
+    ref = oracle.compress_data(vals, cid, cli_error=error)
+    fg, fo = H.parse_bro(bro), H.parse_bro(ref)
+    assert fg[0] == fo[0] and [f[:3] for f in fg[1]] == [f[:3] for f in fo[1]]
+    if all(f[2] != oracle.FFT for f in fg[1]):
+        assert bro == ref
+    # -u: .bro + .vsri -> .wbro + .csv (main.rs:139-173)
+    out = tmp_path / "restored"
+    _run(csvc_bin, "-u", "-o", out, tmp_path / "metric.bro")
+    dec = A.wbro_read(tmp_path / "restored.wbro")
+    assert len(dec) == len(vals)
+    if compressor == "noop":
+        assert np.array_equal(dec, np.sign(vals) * np.floor(np.abs(vals) + 0.5))
+    elif error == 0:
+        # "lossless" keeps every point, and the decoder still rounds to 5 decimals (utils/mod.rs:61-74)
+        assert np.max(np.abs(dec - vals)) <= 5.0001e-6
+        assert np.array_equal(dec, oracle.decompress_data(bro))
+    elif compressor != "constant":
+        assert H.mape(vals, dec) <= error / 100.0
+    assert (tmp_path / "restored.csv").read_text() == VO.samples_to_csv_text(
+        VO.metric_sample_times(index, len(vals)), dec)
+
+
+def test_csv_compressor_flags_and_failures(A, csvc_bin, tmp_path):
+    src = tmp_path / "m.csv"
+    _metric_csv(src, n=300)
+    # --no-compression writes only what was asked for
+    _run(csvc_bin, "--no-compression", "--output-vsri", "-o", tmp_path / "idx.any", src)
+    assert (tmp_path / "idx.vsri").exists() and not (tmp_path / "idx.bro").exists()
+    # clap rejections: exit status 2
+    for args in (["--compressor", "rle", str(src)], ["-e", "51", str(src)], ["-c", "7", str(src)], []):
+        r = subprocess.run([csvc_bin] + args, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2, args
+    # panics of the reference: exit status 101
+    r = subprocess.run([csvc_bin, str(tmp_path / "missing.csv")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101
+    r = subprocess.run([csvc_bin, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101  # "Input is not a file"
+    bad = tmp_path / "bad.csv"
+    bad.write_text("timestamp,value\n1000,1.0\nabc,2.0\n")
+    r = subprocess.run([csvc_bin, str(bad)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101
+    back = tmp_path / "back.csv"  # the second sample is earlier in the day than the first
+    back.write_text("timestamp,value\n1700006500000,1.0\n1700006400000,2.0\n")
+    r = subprocess.run([csvc_bin, str(back)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101
+    # -u without the .vsri next to the .bro: "failed to read vsri"
+    _run(csvc_bin, "--compressor", "noop", src)
+    r = subprocess.run([csvc_bin, "-u", str(tmp_path / "m.bro")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101
+    # -u on something that is not a BRO file does nothing (bro_reader.rs:31-46)
+    r = subprocess.run([csvc_bin, "-u", str(src)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and not (tmp_path / "m.wbro").exists()
