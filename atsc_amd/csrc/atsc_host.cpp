@@ -31,6 +31,9 @@ hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frame
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
                                    uint32_t ws_slots, hipStream_t s);
+hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
+                                uint32_t *hist_cursor, const uint32_t *class_first,
+                                const uint32_t *class_count, int n_classes, hipStream_t s);
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
@@ -59,6 +62,7 @@ struct atsc_ctx {
     hipStream_t diag_stream = nullptr;
     bool want_diag = false;
     hipStream_t pack_stream = nullptr;  // created by the first pipelined call
+    bool adaptive_order = true;         // pipelined calls start a class's costliest frames first
     int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
     // optional timing of the dominant k_compress launch (HIP events on the launch stream)
     bool profiling = false;
@@ -118,6 +122,13 @@ struct atsc_plan {
     mutable hipEvent_t ev_codec[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr};
     mutable bool pack_pending[2] = {false, false};
     uint64_t slots_bytes = 0;
+    // scheduling hint of the pipelined path: clocks per frame in the last batch, and the launch
+    // order derived from them (one per scratch set; written by k_order_by_cost on the pack stream)
+    mutable uint32_t *d_cost = nullptr;
+    mutable uint8_t *d_bucket = nullptr;
+    mutable uint32_t *d_hist = nullptr;  // histogram + cursors of k_cost_hist / k_cost_scatter
+    mutable uint32_t *d_ids_adapt[2] = {nullptr, nullptr};
+    mutable bool adapt_valid[2] = {false, false};
 };
 
 struct atsc_dplan {
@@ -338,6 +349,7 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
     c->device = device;
     c->want_diag = getenv("ATSC_DIAG") != nullptr;
     if (const char *ds = getenv("ATSC_DEBUG_STOP")) c->debug_stop = atoi(ds);
+    if (getenv("ATSC_NO_ADAPTIVE_ORDER")) c->adaptive_order = false;
     *out = c;
     return ATSC_OK;
 }
@@ -424,6 +436,11 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     if (p->alt.d_slots) (void)hipFree(p->alt.d_slots);
     if (p->alt.d_local) (void)hipFree(p->alt.d_local);
     if (p->alt.d_blocksum) (void)hipFree(p->alt.d_blocksum);
+    if (p->d_cost) (void)hipFree(p->d_cost);
+    if (p->d_bucket) (void)hipFree(p->d_bucket);
+    if (p->d_hist) (void)hipFree(p->d_hist);
+    if (p->d_ids_adapt[0]) (void)hipFree(p->d_ids_adapt[0]);
+    if (p->d_ids_adapt[1]) (void)hipFree(p->d_ids_adapt[1]);
     for (int k = 0; k < 2; ++k) {
         if (p->ev_codec[k]) (void)hipEventDestroy(p->ev_codec[k]);
         if (p->ev_pack[k]) (void)hipEventDestroy(p->ev_pack[k]);
@@ -675,6 +692,12 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_slots, plan->slots_bytes));
             HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_local, plan->n_frames * sizeof(uint32_t)));
             HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_blocksum, (nb + 1) * sizeof(uint64_t)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->d_cost, plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMemset(plan->d_cost, 0, plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->d_bucket, plan->n_frames));
+            HIPCHK(ctx, hipMalloc((void **)&plan->d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->d_ids_adapt[0], plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&plan->d_ids_adapt[1], plan->n_frames * sizeof(uint32_t)));
             for (int i = 0; i < 2; ++i) {
                 // ev_codec rides on the last k_compress dispatch (hipExtLaunchKernel stop event)
                 HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_codec[i], hipEventReleaseToDevice));
@@ -699,6 +722,9 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             }
     }
     hipEvent_t codec_done = nullptr;  // already attached to the last codec dispatch, if any
+    const bool adapt = pipelined && ctx->adaptive_order;
+    bool want_order = false;  // set once the main launches (which record the costs) are enqueued
+    const uint32_t *ids_main = (adapt && plan->adapt_valid[k]) ? plan->d_ids_adapt[k] : plan->d_ids;
     auto pack = [&]() -> int {
         if (pipelined) {
             if (!codec_done) {
@@ -711,6 +737,14 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
                                    S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err, ps);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
         if (pipelined) {
+            if (adapt && want_order) {
+                // launch order for the call after next (same scratch set): costliest frames first
+                e = launch_order_by_cost(plan->d_ids, plan->d_ids_adapt[k], plan->d_cost, plan->d_bucket,
+                                         plan->d_hist, plan->class_first.data(), plan->class_count.data(),
+                                         CLASS_LARGE, ps);
+                if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch order_by_cost", e);
+                plan->adapt_valid[k] = true;
+            }
             HIPCHK(ctx, hipEventRecord(plan->ev_pack[k], ps));
             plan->pack_pending[k] = true;
         }
@@ -754,6 +788,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.trial = 0;
     prm.trial_min_n = 0;
     prm.trial_res = nullptr;
+    prm.cost = nullptr;
     if (compressor == ATSC_AUTO && sample_level > 0) {
         if (!plan->trials[sample_level]) {
             SubPlan *t = nullptr;
@@ -786,6 +821,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         return pack();
     }
     int dominant = 0, last_c = 0;
+    if (adapt) { prm.cost = plan->d_cost; want_order = true; }
     for (int c = 1; c < N_CLASSES; ++c)
         if (plan->class_count[c] > plan->class_count[dominant]) dominant = c;
     for (int c = 0; c < N_CLASSES; ++c)
@@ -819,11 +855,14 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
                                       plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
                                       plan->tabs.d_tw, prm, S.d_slots, S.d_res, d_diag, plan->d_ws,
                                       plan->ws_stride, plan->ws_slots, s);
-        else
+        else {
+            UniArgs u = plan->class_uni[c];
+            u.adaptive = (ids_main != plan->d_ids) ? 1u : 0u;
             e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
-                                      plan->d_frames, plan->d_ids + plan->class_first[c],
+                                      plan->d_frames, ids_main + plan->class_first[c],
                                       plan->tabs.d_plans, plan->tabs.d_tw, prm, S.d_slots,
-                                      S.d_res, d_diag, plan->class_uni[c], s, ev0, ev1);
+                                      S.d_res, d_diag, u, s, ev0, ev1);
+        }
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_compress", e);
         if (bracket) HIPCHK(ctx, hipEventRecord(ev1, s));
         if (timed) ctx->ev_used++;
@@ -847,6 +886,12 @@ extern "C" int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *
 {
     return compress_impl(ctx, plan, d_samples, compressor, bounded, max_error, sample_level, d_body,
                          body_cap, d_rec_off, d_chosen, d_err, stream, true);
+}
+extern "C" int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on)
+{
+    if (!ctx) return ATSC_E_INVALID;
+    ctx->adaptive_order = on != 0;
+    return ATSC_OK;
 }
 extern "C" int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream)
 {

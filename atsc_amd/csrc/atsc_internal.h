@@ -60,6 +60,7 @@ struct KParams {
                                  //    shortcut, no payload emission, only res[].chosen matters
     uint32_t trial_min_n;        // COMPRESSION_SPEED[level]; frames at least this long use the trial's codec
     const DevResult *trial_res;  // results of the trial launch (indexed like the frames), or null
+    uint32_t *cost;              // per frame: shader clocks / 64 this launch took (scheduling hint), or null
 };
 
 // Uniform launch: every frame of the class has the same length and frame f of the class sits at
@@ -67,6 +68,7 @@ struct KParams {
 // computed instead of being loaded through ids[] -> frames[] (two dependent loads per workgroup).
 struct UniArgs {
     uint32_t enabled;
+    uint32_t adaptive;  // the class is walked in the order of ids[] (costliest frames first)
     uint32_t fid0;
     uint64_t sample_off0;
     uint64_t slot_off0;

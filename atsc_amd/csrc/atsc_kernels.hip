@@ -25,6 +25,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "atsc_device.h"
 
@@ -183,10 +184,12 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     const uint32_t tid = threadIdx.x;
     uint32_t fid;
     DevFrame fr;
+    const long long t_start = prm.cost ? clock64() : 0;
     if (uni.enabled) {
-        fid = uni.fid0 + blockIdx.x;
-        fr.sample_off = uni.sample_off0 + (uint64_t)blockIdx.x * uni.n;
-        fr.slot_off = uni.slot_off0 + (uint64_t)blockIdx.x * uni.slot_stride;
+        const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0 : blockIdx.x;
+        fid = uni.fid0 + r;
+        fr.sample_off = uni.sample_off0 + (uint64_t)r * uni.n;
+        fr.slot_off = uni.slot_off0 + (uint64_t)r * uni.slot_stride;
         fr.n = uni.n;
         fr.plan = uni.plan;
     } else {
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             res[fid].len = 2 + vb;
             res[fid].chosen = ATSC_CONSTANT;
             if (diag) diag[fid] = dg;
+            if (prm.cost) prm.cost[fid] = (uint32_t)min((unsigned long long)(clock64() - t_start) >> 6, 0xFFFFFFFFull);
         }
         return;
     }
@@ -1011,7 +1015,86 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         res[fid].len = out_len;
         res[fid].chosen = (uint32_t)chosen;
         if (diag) diag[fid] = dg;
+        if (prm.cost) prm.cost[fid] = (uint32_t)min((unsigned long long)(clock64() - t_start) >> 6, 0xFFFFFFFFull);
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// Scheduling hint.  A frame costs between a few hundred and tens of thousands of instruction slots
+// depending on how far its ladders run, and workgroups start in grid order: when the costliest
+// frames start last the GPU drains half empty.  k_order_by_cost rewrites a class's launch order,
+// costliest first, from the clocks each frame took in the previous batch of the same plan (slot i
+// of a recurring batch is the same series one window later).  Only the order of execution changes:
+// every result is written at its frame's own position.
+// --------------------------------------------------------------------------------------------
+struct ClassSpans {
+    uint32_t first[8], count[8];  // spans of the small-frame classes in ids[] order, ascending `first`
+    uint32_t n_spans, total;      // total = entries covered (the spans are contiguous from 0)
+};
+DEVI uint32_t cost_bucket(uint32_t c)  // 4 buckets per octave, 0..63
+{
+    if (c == 0) return 0;
+    const uint32_t msb = 31u - (uint32_t)__clz((int)c);
+    const uint32_t sub = msb >= 2 ? (c >> (msb - 2)) & 3u : 0u;
+    return min(63u, msb * 4u + sub);
+}
+DEVI uint32_t span_of(const ClassSpans &sp, uint32_t i)
+{
+    uint32_t c = 0;
+    for (uint32_t k = 1; k < sp.n_spans; ++k)
+        if (i >= sp.first[k]) c = k;
+    return c;
+}
+// pass 1: bucket of every entry (fixed here: cost[] may already be rewritten by the next batch while
+// pass 2 runs) and the per-span histogram, pre-aggregated in LDS.  hist is zero on entry.
+__global__ __launch_bounds__(256) void k_cost_hist(const uint32_t *__restrict__ ids_src,
+                                                   const uint32_t *cost, uint8_t *__restrict__ bkt,
+                                                   uint32_t *__restrict__ hist, const ClassSpans sp)
+{
+    __shared__ uint32_t h[8 * 64];
+    for (uint32_t k = threadIdx.x; k < 8 * 64; k += 256) h[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < sp.total) {
+        const uint32_t b = cost_bucket(cost[ids_src[i]]);
+        bkt[i] = (uint8_t)b;
+        atomicAdd(&h[span_of(sp, i) * 64 + b], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 8 * 64; k += 256)
+        if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+// pass 2: every workgroup derives the bucket bases of its spans from the histogram (costliest bucket
+// first), reserves room for its own entries with one atomic per non-empty bucket, and scatters.
+// The order inside a bucket is whatever the atomics give: it only affects scheduling.
+__global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict__ ids_src,
+                                                      uint32_t *__restrict__ ids_dst,
+                                                      const uint8_t *__restrict__ bkt,
+                                                      const uint32_t *__restrict__ hist,
+                                                      uint32_t *__restrict__ cursor, const ClassSpans sp)
+{
+    __shared__ uint32_t base[8 * 64], cnt[8 * 64], res[8 * 64];
+    for (uint32_t k = threadIdx.x; k < 8 * 64; k += 256) cnt[k] = 0;
+    if (threadIdx.x < sp.n_spans) {
+        uint32_t acc = sp.first[threadIdx.x];
+        for (int b = 63; b >= 0; --b) {
+            base[threadIdx.x * 64 + b] = acc;
+            acc += hist[threadIdx.x * 64 + b];
+        }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    const bool live = i < sp.total;
+    if (live) {
+        key = span_of(sp, i) * 64 + bkt[i];
+        rank = atomicAdd(&cnt[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 8 * 64; k += 256)
+        if (cnt[k]) res[k] = atomicAdd(&cursor[k], cnt[k]);
+    __syncthreads();
+    if (live) ids_dst[base[key] + res[key] + rank] = ids_src[i];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1076,10 +1159,13 @@ __global__ __launch_bounds__(256) void k_pack_scan2(uint64_t *__restrict__ block
     if (threadIdx.x == 0) blocksum[nb] = carry;
 }
 
-// 16 lanes per frame (4 frames per wavefront, 16 per workgroup): header varints + payload copy; also
+// 8 lanes per frame (8 frames per wavefront, 32 per workgroup): header varints + payload copy in
+// 8-byte pieces (slots are 16-byte aligned; the destination is not, gfx950 stores it unaligned); also
 // the user-visible side arrays.  FUSED: blocksum[] still holds the per-chunk totals (k_pack_scan2 was
 // skipped, at most 64 chunks); every wavefront adds up the totals of the chunks before its own (a
-// workgroup never straddles a chunk: PACK_CHUNK is a multiple of 16).
+// workgroup never straddles a chunk: PACK_CHUNK is a multiple of 32).
+constexpr int EMIT_LANES = 8;
+constexpr int EMIT_FRAMES = 256 / EMIT_LANES;  // frames per workgroup
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_pack_emit(
     const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
@@ -1087,9 +1173,9 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     const uint8_t *__restrict__ slots, uint8_t *__restrict__ body, uint64_t body_cap,
     uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen, double *__restrict__ err)
 {
-    const uint64_t f = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const uint32_t lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
-    const uint32_t chunk = (uint32_t)(((uint64_t)blockIdx.x * 16) / PACK_CHUNK);
+    const uint64_t f = (uint64_t)blockIdx.x * EMIT_FRAMES + (threadIdx.x / EMIT_LANES);
+    const uint32_t lane = threadIdx.x & 63, l8 = threadIdx.x & (EMIT_LANES - 1);
+    const uint32_t chunk = (uint32_t)(((uint64_t)blockIdx.x * EMIT_FRAMES) / PACK_CHUNK);
     uint64_t base;
     if (FUSED) {
         const uint64_t v = lane < chunk ? blocksum[lane] : 0;
@@ -1104,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     const DevResult r = res[f];
     const uint64_t off = base + local[f];
     const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
-    if (l16 == 0) {
+    if (l8 == 0) {
         rec_off[f] = off;
         if (chosen) chosen[f] = (uint8_t)r.chosen;
         if (err) err[f] = r.err;
@@ -1112,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     }
     if (off + hl + r.len > body_cap) return;  // caller sized d_body too small; rec_off tells
     uint8_t *dst = body + off;
-    if (l16 == 0) {
+    if (l8 == 0) {
         uint8_t *p = dst;
         *p++ = 41;  // frame_size: size_of_val sum, always 41 on 64-bit (frame/mod.rs:50-56)
         p += put_varint(p, fr.n);
@@ -1120,7 +1206,13 @@ __global__ __launch_bounds__(256) void k_pack_emit(
         p += put_varint(p, r.len);
     }
     const uint8_t *src = slots + fr.slot_off;
-    for (uint32_t b = l16; b < r.len; b += 16) dst[hl + b] = src[b];
+    uint8_t *pd = dst + hl;
+    const uint32_t whole = r.len & ~7u;
+    for (uint32_t b = l8 * 8; b < whole; b += 8 * EMIT_LANES) {
+        const uint64_t v = *(const uint64_t *)(src + b);
+        __builtin_memcpy(pd + b, &v, 8);
+    }
+    if (whole + l8 < r.len) pd[whole + l8] = src[whole + l8];  // at most 7 trailing bytes
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1185,7 +1277,7 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
-    const dim3 eg((uint32_t)((n_frames + 15) / 16));
+    const dim3 eg((uint32_t)((n_frames + EMIT_FRAMES - 1) / EMIT_FRAMES));
     if (nb <= 64) {
         hipLaunchKernelGGL(k_pack_emit<true>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
                            slots, body, body_cap, rec_off, chosen, err);
@@ -1194,6 +1286,30 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
         hipLaunchKernelGGL(k_pack_emit<false>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
                            slots, body, body_cap, rec_off, chosen, err);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
+                                uint32_t *hist_cursor /* 2 * 8 * 64 u32 */, const uint32_t *class_first,
+                                const uint32_t *class_count, int n_classes, hipStream_t s)
+{
+    ClassSpans sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int c = 0; c < n_classes && sp.n_spans < 8; ++c)
+        if (class_count[c]) {
+            if (class_first[c] != sp.total) return hipErrorInvalidValue;  // spans must be contiguous from 0
+            sp.first[sp.n_spans] = class_first[c];
+            sp.count[sp.n_spans] = class_count[c];
+            sp.total += class_count[c];
+            ++sp.n_spans;
+        }
+    if (!sp.total) return hipSuccess;
+    hipError_t e = hipMemsetAsync(hist_cursor, 0, 2 * 8 * 64 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((sp.total + 255) / 256);
+    hipLaunchKernelGGL(k_cost_hist, grid, dim3(256), 0, s, ids_src, cost, bkt, hist_cursor, sp);
+    hipLaunchKernelGGL(k_cost_scatter, grid, dim3(256), 0, s, ids_src, ids_dst, bkt, hist_cursor,
+                       hist_cursor + 8 * 64, sp);
     return hipGetLastError();
 }
 

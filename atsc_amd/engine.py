@@ -40,6 +40,10 @@ class Context:
         capi.check(capi.lib().atsc_ctx_last_diag(self._h, arr, n_frames), self._h)
         return arr
 
+    def set_adaptive_order(self, on=True):
+        """Pipelined calls start a class's costliest frames (previous batch's clocks) first."""
+        capi.check(capi.lib().atsc_ctx_set_adaptive_order(self._h, int(on)), self._h)
+
     def set_profiling(self, on=True):
         capi.check(capi.lib().atsc_ctx_set_profiling(self._h, int(on)), self._h)
 

@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
                          "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
+    ap.add_argument("--no-adaptive-order", action="store_true",
+                    help="start the frames in index order instead of costliest-first (cost = shader "
+                         "clocks of the same frame slot in the previous step)")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +121,8 @@ def main():
     # of step i runs on the context's pack stream and overlaps the frame codecs of step i+1 (and, for
     # N > 1, so does the gather of step i, issued from a side stream that waits for that packing).
     pipelined = not args.no_pipeline
+    if args.no_adaptive_order:
+        ctx.set_adaptive_order(False)
     outs2 = [outs, plan.alloc_outputs(torch, dev)]
     pg = None
     gstream = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -241,8 +246,11 @@ def main():
                 "encoded_bytes_rank0": body_bytes,
                 "parallelism": "frames sharded by rank (%d), RCCL gather of records to rank 0" % world
                                if world > 1 else "single GPU",
-                "pipeline": "record packing of step i on the pack stream overlaps the codecs of step i+1 "
-                            "(two scratch + output sets)" if pipelined else "single stream",
+                "pipeline": ("record packing of step i on the pack stream overlaps the codecs of step i+1 "
+                             "(two scratch + output sets)" +
+                             ("" if args.no_adaptive_order else "; within a launch the frames start costliest "
+                              "first, cost = shader clocks of the same frame slot two steps earlier"))
+                            if pipelined else "single stream",
             },
             "roofline": {
                 "bound": "hbm",

@@ -129,6 +129,11 @@ int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan, const
                                      int sample_level, uint8_t *d_body, uint64_t body_cap,
                                      uint64_t *d_rec_off, uint8_t *d_chosen, double *d_err,
                                      void *stream);
+/* Pipelined calls record how many shader clocks every frame took and start the next batches of the
+ * same plan with a class's costliest frames first (frame i of a recurring batch is the same series,
+ * one window later); otherwise the frames that run longest start last and the GPU drains half
+ * empty.  Only the order of execution changes, never a result.  On by default; 0 turns it off. */
+int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on);
 /* Makes `stream` wait (device side, no host block) for every packing enqueued so far by
  * atsc_compress_plan_dev_pipelined on `plan`. */
 int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream);

@@ -600,3 +600,41 @@ def test_idw_one_131072_frame(ctx, A, oracle):
     s = P.compare_batch(oracle, ctx, x, off, A.IDW, True, ME5)
     _log(P.assert_summary(s, 1, "idw 131072"))
     assert s["tol"] == 0 and s["boundary"] == 0
+
+
+def test_pipelined_adaptive_order_mixed_lengths(ctx, A):
+    """Cost-ordered launches (atsc_ctx_set_adaptive_order) over a plan with several frame-length
+    classes and a large frame: eight pipelined batches, alternating between two data sets, give the
+    bytes of plain calls; the launch order never shows in the results."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    lens = [256] * 700 + [64] * 90 + [300] * 40 + [512] * 60 + [1000] * 30 + [2048] * 12 + [4096] * 6 + [8192] + [100] * 50
+    rng = np.random.default_rng(5)
+    rng.shuffle(lens)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(off[-1])
+    plan = ctx.plan(off)
+    stream = torch.cuda.current_stream().cuda_stream
+    data = [torch.from_numpy(H.synth_series(300 + b, n, block=4096)).to(dev) for b in range(2)]
+
+    def fetch(o):
+        total = int(o["rec_off"][-1].item())
+        return o["body"][:total].cpu().numpy().tobytes(), o["chosen"].cpu().numpy().copy()
+
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for d_x in data:
+        plan.compress(d_x, o, A.AUTO, True, ME5, 0, stream)
+        torch.cuda.synchronize()
+        ref.append(fetch(o))
+    ctx.set_adaptive_order(True)
+    outs = [plan.alloc_outputs(torch, dev) for _ in range(8)]
+    for b in range(8):
+        plan.compress(data[(b // 3) % 2], outs[b], A.AUTO, True, ME5, 0, stream, pipelined=True)
+    plan.join(stream)
+    torch.cuda.current_stream().synchronize()
+    for b in range(8):
+        got = fetch(outs[b])
+        want = ref[(b // 3) % 2]
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), b
