@@ -31,6 +31,26 @@ ERROR_PCT = 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# one worker of the all-core CPU baseline: frames [f0, f1) of the saved sample through the oracle,
+# started at the agreed time; prints "<seconds late> <end time>"
+_CPU_WORKER = r"""
+import sys, time
+import numpy as np
+root, path, f0, f1, me, start_at = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), float(sys.argv[6])
+sys.path.insert(0, root)
+from oracle import oracle as orc
+F = %d
+xs = np.ascontiguousarray(np.load(path, mmap_mode="r")[f0 * F:f1 * F])
+so = np.arange(0, (f1 - f0) * F + 1, F, dtype=np.uint64)
+orc.stream_compress(xs[:F * 8], so[:9], orc.AUTO, True, me, 0)
+late = max(0.0, time.time() - start_at)
+while time.time() < start_at:
+    time.sleep(0.001)
+orc.stream_compress(xs, so, orc.AUTO, True, me, 0)
+print(late, time.time())
+""" % FRAME
+
+
 def cpu_baseline(x, off, me, frames_per_block=256, blocks=160):
     """Times the CPU oracle (C restatement of the reference algorithm, single thread) on a bounded
     sample of the same workload: the first `frames_per_block` frames of each of the first `blocks`
@@ -49,7 +69,45 @@ def cpu_baseline(x, off, me, frames_per_block=256, blocks=160):
     t0 = time.perf_counter()
     bro, _, _ = orc.stream_compress(xs, so, orc.AUTO, True, me, 0)
     dt = time.perf_counter() - t0
+    # The same sample over every host core the process may use: one fresh `python -c` worker per core
+    # (they never see the GPU context), released together at an agreed wall-clock time; bounded by a
+    # timeout, after which the workers started here are killed by PID and the figure is left out.
+    # The reference itself is single-threaded, so this is extra information, not `value`.
+    import subprocess
+    import tempfile
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    nfr = len(idx)
+    cuts = [nfr * k // cores for k in range(cores + 1)]
+    all_cores = None
+    procs = []
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.npy")
+            np.save(path, xs)
+            start_at = time.time() + 6.0
+            for k in range(cores):
+                if cuts[k + 1] > cuts[k]:
+                    procs.append(subprocess.Popen(
+                        [sys.executable, "-c", _CPU_WORKER, ROOT, path, str(cuts[k]), str(cuts[k + 1]), repr(me),
+                         repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            ends = []
+            for pr in procs:
+                out, _ = pr.communicate(timeout=180)
+                if pr.returncode != 0:
+                    raise RuntimeError("worker exit %d" % pr.returncode)
+                late, end = out.split()
+                if float(late) > 0:
+                    raise RuntimeError("a worker was not ready at the start time")
+                ends.append(float(end))
+            all_cores = {"value": len(xs) / (max(ends) - start_at) / 1e6, "unit": "Msamples/s", "cores": len(procs)}
+    except Exception as e:  # pragma: no cover - the single-thread figure stands on its own
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        sys.stderr.write("all-core CPU baseline skipped: %r\n" % (e,))
     return {
+        "all_cores": all_cores,
         "value": len(xs) / dt / 1e6,
         "unit": "Msamples/s",
         "cores": 1,
