@@ -246,6 +246,27 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         if (l != 1) return ATSC_E_INVALID;
         p.nstages = s;
     }
+    {
+        const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+        const uint32_t dj1 = std::max(n / 10, 1u), dj2 = std::max(n / 100, 1u);
+        uint32_t jump = 0;
+        p.inv_n = 1.0 / (double)n;
+        for (uint32_t t = 0; t < 23; ++t) {
+            const uint32_t pts = base + jump;
+            const uint32_t step = std::max(n / pts, 1u);
+            const uint32_t cnt = (n + step - 1) / step;
+            const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+            p.pstep[t] = step;
+            p.pK[t] = K;
+            p.pmagic[t] = step >= 2 ? (uint32_t)(0x100000000ull / step) + 1u : 0u;
+            const int64_t gap = (int64_t)(n - 1) - ((int64_t)K - 2) * (int64_t)step;
+            p.pgap[t] = (K >= 2 && gap > 0) ? (uint32_t)gap : 1u;
+            p.pry[t] = 1.0 / (double)step;
+            p.pryL[t] = 1.0 / (double)p.pgap[t];
+            if (t + 1 <= 17) jump += dj1;
+            else if (t + 1 <= 22) jump += dj2;
+        }
+    }
     p.p2bins = pow2_ge(p.bins);
     p.p2n = pow2_ge(n);
     p.magicL = p.L >= 2 ? (uint32_t)(0x100000000ull / p.L) + 1u : 0u;

@@ -30,6 +30,16 @@ struct DevPlan {
     // later reused for spline tables, RLE run records and the RLE hash table.
     uint32_t o_xs, o_tw, o_ab, ab_half, ab_bytes, o_sel, o_aux, o_red;
     uint64_t tw_off;   // offset (in float2 entries) of this L's table in the twiddle pool
+    // The polynomial ladder of a frame of n samples (polynomial.rs:209-277) visits the same
+    // (points, step, K) sequence whatever the data: points = base + jump, jump += n/10 (trips 1..17)
+    // or n/100 (18..22).  Everything a trip derives from (n, step) is tabulated once per length.
+    double inv_n;         // 1.0 / n
+    double pry[23];       // 1.0 / step
+    double pryL[23];      // 1.0 / gap of the last segment
+    uint32_t pstep[23];   // max(n / points, 1)
+    uint32_t pK[23];      // number of stored points: ceil(n / step) (+1 when the last sample is not a knot)
+    uint32_t pmagic[23];  // floor(2^32 / step) + 1 (step >= 2): i / step without a divide
+    uint32_t pgap[23];    // (n - 1) - (K - 2) * step: length of the last segment
 };
 
 struct DevFrame {

@@ -351,7 +351,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     double poly_err = 0.0;
     bool poly_done = false;
     // exact Polynomial payload size for (step, K): polynomial.rs:54-87
+    uint32_t psz_step = 0, psz_K = 0xFFFFFFFFu, psz = 0;  // last (step, K) sized: asked for up to three times
     auto poly_payload_size = [&](uint32_t step, uint32_t K) -> uint32_t {
+        if (step == psz_step && K == psz_K) return psz;
         uint32_t vb = 0;
         if (bitdepth == 0 || bitdepth == 3) {
             vb = K * (bitdepth == 0 ? 8u : 1u);
@@ -362,7 +364,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             }
             vb = block_sum_u32<W>(vb, red, parity);
         }
-        return 1 + 1 + vlen(K) + vb + 8 + 8 + 1;
+        psz_step = step;
+        psz_K = K;
+        psz = 1 + 1 + vlen(K) + vb + 8 + 8 + 1;
+        return psz;
     };
 
     // ---- RLE (rle.rs:142-189): cheap bound first; exact right away when there are few runs ----
@@ -464,11 +469,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
     bool poly_first = false;
     if (prune && run_fft && run_poly && smax != smin) {
-        const uint32_t base0 = (3 >= n / 100) ? 3 : n / 100;
-        const uint32_t step0 = max(n / base0, 1u);
-        const uint32_t cnt0 = (n + step0 - 1) / step0;
-        const uint32_t K0 = cnt0 + (((cnt0 - 1) * step0 != n - 1) ? 1u : 0u);
-        poly_first = poly_payload_size(step0, K0) < 1 + 1 + 9 * min(P.mf, bins) + 8;
+        poly_first = poly_payload_size(P.pstep[0], P.pK[0]) < 1 + 1 + 9 * min(P.mf, bins) + 8;
     }
     auto eval_poly = [&]() {
         // =========================================================================================
@@ -482,23 +483,18 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             } else if (!prm.bounded) {
                 // Compressor::compress -> polynomial() -> compress_hinted(baseline points), no error loop
                 // (polynomial.rs:307-314,407-413)
-                const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-                poly_step = max(n / base, 1u);
-                const uint32_t cnt = (n + poly_step - 1) / poly_step;
-                poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
+                poly_step = P.pstep[0];
+                poly_K = P.pK[0];
             } else {
-                const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-                const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+                // the (step, K, ...) of every trip come from the per-length table (DevPlan::pstep ...)
                 double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
-            const double inv_n = 1.0 / (double)n;
+            const double inv_n = P.inv_n;
             const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
                 double cur = prm.max_err + 1.0;
-                uint32_t jump = 0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
-                    const uint32_t pts = base + jump;
-                    const uint32_t step = max(n / pts, 1u);
-                    const uint32_t cnt = (n + step - 1) / step;
-                    const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                    const uint32_t ti = poly_trips;  // 0 .. 22
+                    const uint32_t step = P.pstep[ti];
+                    const uint32_t K = P.pK[ti];
                     if (prune && !can_win(poly_payload_size(step, K), 1)) { poly_pruned = true; break; }
                     ++poly_trips;
                     poly_step = step;
@@ -544,10 +540,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         // once, in the crate's operation order (oracle: cubic_hermite), so each sample's
                         // value keeps the oracle's bits.
                         rle_early = false;  // the tangent / basis tables live in AB
-                        const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
-                        const uint32_t gapL = (n - 1) - (K - 2) * step;  // length of the last segment
+                        const uint32_t magic = P.pmagic[ti];
+                        const uint32_t gapL = P.pgap[ti];  // length of the last segment
                         const double stepd = (double)step, gapLd = (double)gapL;
-                        const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                        const double ry = P.pry[ti], ryL = P.pryL[ti];
                         const uint32_t mm_bytes = (16 * K + 15) & ~15u;
                         const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= P.ab_bytes);
                         double4 *hb = (double4 *)(AB + mm_bytes);  // basis (h00, h10, h01, h11) per offset r
@@ -619,18 +615,23 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                                     }
                                 }
                                 double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
-                                if (o < smin) o = smin;
-                                else if (o > smax) o = smax;
+                                if (pfast) {
+                                    o = fmin(fmax(o, smin), smax);  // o is finite: same as the compares
+                                } else {
+                                    if (o < smin) o = smin;
+                                    else if (o > smax) o = smax;
+                                }
                                 s += fabs(o - g[m]) * inv[m];
                             }
                         }
                         s = block_sum_f64<W>(s, red, parity);
                         cur = s * inv_n;
                     }
-                    if (poly_trips <= 17) jump += dj1;
-                    else if (poly_trips <= 22) jump += dj2;
-                    else if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
-                    else { poly_step = 1; poly_K = n; cur = 0.0; break; }
+                    if (poly_trips > 22) {  // polynomial.rs:255-263: the jumps are spent
+                        if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
+                        poly_step = 1; poly_K = n; cur = 0.0;
+                        break;
+                    }
                     if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
                 }
                 poly_err = cur;
