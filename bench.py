@@ -76,7 +76,7 @@ def cpu_baseline(x, off, me, frames_per_block=256, blocks=160):
     import subprocess
     import tempfile
 
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # a one-GPU box's CPU share is 16 cores
     nfr = len(idx)
     cuts = [nfr * k // cores for k in range(cores + 1)]
     all_cores = None
