@@ -421,6 +421,67 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         rle_size = 2 + vlen(D) + hb + rle_ib;
         rle_sorted = true;
     };
+    // One wavefront and at most 16 runs: one run per lane, no LDS scans or sort network.
+    //  build: each lane walks its contiguous share of the samples, a DPP scan places the run ends,
+    //         lane r ranks run r among all runs by (value bits, start) with R broadcast compares and
+    //         drops its record at that rank (AB[0..R) = sorted records, as the general path leaves);
+    //  group: sorted run i sits in lane i; a group head differs from its left neighbour (row_shr:1,
+    //         R <= 16 keeps everything in DPP row 0); the ballot of the heads gives the group count
+    //         and every group's length; header / index bytes are prefix sums across lanes.
+    bool rle_small = false;
+    struct RleLane { uint32_t rec, cnt, hb, D, hb_total; bool head, live; };
+    auto rle_small_build = [&]() {
+        uint32_t *srt = (uint32_t *)AB, *ends = srt + 16;
+        __syncthreads();
+        const uint32_t C = (n + 63) >> 6, j0 = tid * C;
+        uint32_t cnt = 0;
+        for (uint32_t k = 0; k < C; ++k) {
+            const uint32_t j = j0 + k;
+            if (j < n && (j + 1 >= n || xs[j + 1] != xs[j])) ++cnt;
+        }
+        uint32_t pos = wave_incl_scan_u32(cnt) - cnt;
+        for (uint32_t k = 0; k < C; ++k) {
+            const uint32_t j = j0 + k;
+            if (j < n && (j + 1 >= n || xs[j + 1] != xs[j])) ends[pos++] = j;
+        }
+        __syncthreads();
+        const uint32_t R = rle_R;
+        uint32_t rec = 0, klo = 0, khi = 0;
+        if (tid < R) {
+            const uint32_t e = ends[tid], st = tid ? ends[tid - 1] + 1 : 0;
+            rec = (st << 16) | e;
+            const uint64_t key = (uint64_t)__double_as_longlong(xs[e]);
+            klo = (uint32_t)key;
+            khi = (uint32_t)(key >> 32);
+        }
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < R; ++q) {  // runs are in start order: q < tid  <=>  start_q < start_tid
+            const uint32_t qlo = (uint32_t)__builtin_amdgcn_readlane((int)klo, (int)q);
+            const uint32_t qhi = (uint32_t)__builtin_amdgcn_readlane((int)khi, (int)q);
+            const bool less = qhi < khi || (qhi == khi && (qlo < klo || (qlo == klo && q < tid)));
+            rank += less ? 1u : 0u;
+        }
+        if (tid < R) srt[rank] = rec;
+        __syncthreads();
+    };
+    auto rle_small_group = [&]() -> RleLane {
+        const uint32_t *srt = (const uint32_t *)AB;
+        const uint32_t R = rle_R;
+        RleLane g;
+        g.live = tid < R;
+        g.rec = g.live ? srt[tid] : 0u;
+        const uint64_t key = g.live ? (uint64_t)__double_as_longlong(xs[g.rec & 0xffffu]) : 0ull;
+        const uint32_t plo = dpp_u32<0x111, 0xf>((uint32_t)key), phi = dpp_u32<0x111, 0xf>((uint32_t)(key >> 32));
+        g.head = g.live && (tid == 0 || plo != (uint32_t)key || phi != (uint32_t)(key >> 32));
+        const uint64_t hm = __ballot(g.head);
+        g.D = (uint32_t)__popcll(hm);
+        const uint64_t after = (tid < 63) ? (hm >> (tid + 1)) : 0ull;
+        const uint32_t next = after ? tid + 1 + (uint32_t)__builtin_ctzll(after) : R;
+        g.cnt = next - tid;
+        g.hb = g.head ? value_bytes(bitdepth, xs[g.rec & 0xffffu]) + vlen(g.cnt) : 0u;
+        g.hb_total = wave_sum_u32(g.hb);
+        return g;
+    };
     if (run_rle) {
         // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
         uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
@@ -431,7 +492,15 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         rle_ib = pk >> 13;
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
         rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * (minval + 1);
-        if (mode == ATSC_RLE) {
+        if (W == 1 && rle_R <= 16 && P.ab_bytes >= 128) {
+            rle_small_build();
+            const RleLane g = rle_small_group();
+            rle_D = g.D;
+            rle_size = 2 + vlen(g.D) + g.hb_total + rle_ib;
+            rle_small = true;
+            rle_early = true;  // AB[0..R) stays valid until a ladder reuses AB
+            if (prune) offer(rle_size, 2);
+        } else if (mode == ATSC_RLE) {
             rle_sort_and_group(rrec_std, rhp_std, rph_std);
             rle_sorted = true;
         } else if (rle_R <= 64 && 12 * rle_R + 16 <= P.ab_bytes) {
@@ -488,8 +557,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             } else {
                 // the (step, K, ...) of every trip come from the per-length table (DevPlan::pstep ...)
                 double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
-            const double inv_n = P.inv_n;
-            const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
+                const double inv_n = P.inv_n;
+                const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
                 double cur = prm.max_err + 1.0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
                     const uint32_t ti = poly_trips;  // 0 .. 22
@@ -504,7 +573,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         // every sample sums over ALL K points in ascending order; an exact hit returns the
                         // point's value.  O(n K) per trip, forced `--compressor idw` only.
                         double s = 0.0;
-    #pragma unroll
+#pragma unroll
                         for (int m = 0; m < SPL; ++m) {
                             const uint32_t j = tid + m * T;
                             if (j >= pre && j < pre + n) {
@@ -578,7 +647,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         }
                         __syncthreads();
                         double s = 0.0;
-    #pragma unroll
+#pragma unroll
                         for (int m = 0; m < SPL; ++m) {
                             const uint32_t j = tid + m * T;
                             if (j >= pre && j < pre + n) {
@@ -846,35 +915,35 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     // ---- RLE with many runs: exact size only if its bound can still win ----
     if (run_rle && rle_pending) {
         if (!prune || can_win(rle_lb, 2)) {
-                // Exact size without sorting: count the distinct run values and their multiplicities
-                // in an LDS hash table (AB is free: ab_bytes / 4 >= 2n slots of run-end indices).
-                uint32_t *tab = (uint32_t *)AB;
-                const uint32_t H = P.ab_bytes >> 2;
-                __syncthreads();
-                for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
-                for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
-                __syncthreads();
-                uint32_t dnew = 0;
-                for (uint32_t j = tid; j < n; j += T) {
-                    if (j + 1 >= n || xs[j + 1] != xs[j]) {
-                        const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
-                        uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
-                        for (;;) {
-                            const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
-                            if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
-                            if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
-                            h = (h + 1 == H) ? 0 : h + 1;
-                        }
+            // Exact size without sorting: count the distinct run values and their multiplicities
+            // in an LDS hash table (AB is free: ab_bytes / 4 >= 2n slots of run-end indices).
+            uint32_t *tab = (uint32_t *)AB;
+            const uint32_t H = P.ab_bytes >> 2;
+            __syncthreads();
+            for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
+            for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
+            __syncthreads();
+            uint32_t dnew = 0;
+            for (uint32_t j = tid; j < n; j += T) {
+                if (j + 1 >= n || xs[j + 1] != xs[j]) {
+                    const uint64_t key = (uint64_t)__double_as_longlong(xs[j]);
+                    uint32_t h = __umulhi(((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u, H);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, j);
+                        if (old == 0xFFFFFFFFu) { atomicAdd(&aux[j], 1u); ++dnew; break; }
+                        if ((uint64_t)__double_as_longlong(xs[old]) == key) { atomicAdd(&aux[old], 1u); break; }
+                        h = (h + 1 == H) ? 0 : h + 1;
                     }
                 }
-                __syncthreads();
-                uint32_t hb = 0;
-                for (uint32_t j = tid; j < n; j += T)
-                    if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
-                // (distinct << 18 | header bytes): header bytes <= 11 * 4096 < 2^18
-                const uint32_t pk2 = block_sum_u32<W>((dnew << 18) | hb, red, parity);
-                rle_D = pk2 >> 18;
-                rle_size = 2 + vlen(rle_D) + (pk2 & 0x3ffffu) + rle_ib;
+            }
+            __syncthreads();
+            uint32_t hb = 0;
+            for (uint32_t j = tid; j < n; j += T)
+                if (aux[j]) hb += value_bytes(bitdepth, xs[j]) + vlen(aux[j]);
+            // (distinct << 18 | header bytes): header bytes <= 11 * 4096 < 2^18
+            const uint32_t pk2 = block_sum_u32<W>((dnew << 18) | hb, red, parity);
+            rle_D = pk2 >> 18;
+            rle_size = 2 + vlen(rle_D) + (pk2 & 0x3ffffu) + rle_ib;
             if (prune) offer(rle_size, 2);
         } else {
             rle_size = rle_lb;  // a lower bound that already cannot win
@@ -966,6 +1035,25 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             out[hdr + body + 16] = (uint8_t)poly_step;  // `step as u8`
         }
         out_len = hdr + body + 17;
+    } else if (rle_small) {  // RLE with one run per lane: rle.rs:40-67
+        if (!rle_early) rle_small_build();  // a ladder overwrote the sorted records
+        const RleLane g = rle_small_group();
+        const uint32_t hdr = 2 + vlen(g.D);
+        const uint32_t st = g.rec >> 16, vl = g.live ? vlen(st) : 0u;
+        const uint32_t vls = wave_incl_scan_u32(vl);  // index varint bytes up to and including this run
+        const uint32_t hbs = wave_incl_scan_u32(g.hb);  // header bytes up to and including this run's group
+        if (g.head) {
+            uint8_t *p = out + hdr + (hbs - g.hb) + (vls - vl);
+            p += put_value(p, bitdepth, xs[g.rec & 0xffffu]);
+            put_varint(p, g.cnt);
+        }
+        if (g.live) put_varint(out + hdr + hbs + (vls - vl), st);
+        if (tid == 0) {
+            out[0] = 60;
+            out[1] = (uint8_t)bitdepth;
+            put_varint(out + 2, g.D);
+        }
+        out_len = hdr + g.hb_total + (uint32_t)__builtin_amdgcn_readlane((int)vls, 63);
     } else {  // RLE: rle.rs:40-67
         // runs are sorted by (value bits, start); rhp = hp[]; rph = hb[]
         uint32_t *rrec = rrec_std, *rhp = rhp_std, *rph = rph_std;

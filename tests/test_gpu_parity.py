@@ -638,3 +638,42 @@ def test_pipelined_adaptive_order_mixed_lengths(ctx, A):
         got = fetch(outs[b])
         want = ref[(b // 3) % 2]
         assert got[0] == want[0] and np.array_equal(got[1], want[1]), b
+
+
+# ---------------------------------------------------------------------------------------
+# RLE with few runs (one run per lane on the GPU): grouping, ordering and byte layout
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_rle_few_runs_fuzz(ctx, A, oracle, seed):
+    rng = np.random.default_rng(seed)
+    pools = [np.array([0.0, -0.0, 1.0, -1.0, 2.5, 1e300, -1e-300, 255.0, 256.0, 65535.0, 70000.0, -3.0]),
+             np.arange(0, 9, dtype=np.float64), np.array([7.0, 7.5]), np.array([100.0, 200.0, 300.0, 100000.0])]
+    xs, offs = [], [0]
+    for _ in range(260):
+        n = int(rng.choice([1, 2, 3, 17, 64, 100, 128, 200, 256, 300, 512]))
+        runs = int(rng.integers(1, min(n, 20) + 1))
+        pool = pools[int(rng.integers(0, len(pools)))]
+        cuts = np.sort(rng.choice(np.arange(1, n), size=runs - 1, replace=False)) if runs > 1 else np.array([], dtype=int)
+        bounds = np.concatenate([[0], cuts, [n]]).astype(int)
+        f = np.empty(n)
+        prev = None
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            v = pool[int(rng.integers(0, len(pool)))]
+            while prev is not None and v == prev and len(pool) > 1:  # adjacent runs must differ (== compare)
+                v = pool[int(rng.integers(0, len(pool)))]
+            f[a:b] = v
+            prev = v
+        xs.append(f)
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    for comp, bounded in ((A.RLE, False), (A.AUTO, True)):
+        s = P.compare_batch(oracle, ctx, x, off, comp, bounded, ME5)
+        _log(P.assert_summary(s, len(off) - 1, "rle few runs seed %d comp %d codecs %s" % (seed, comp, s["codecs"])))
+        if comp == A.RLE:
+            assert s["tol"] == 0 and s["boundary"] == 0
+            out = ctx.decompress_host(s["records"])
+            # not compared with x: at integer bitdepths the reference loses the sign of -0.0 and
+            # saturates integer-valued samples beyond i32; the decode has to equal the oracle's
+            ref = oracle.decompress_data(A.bro_prefix(len(off) - 1) + s["records"])
+            assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
