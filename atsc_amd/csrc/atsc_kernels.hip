@@ -112,6 +112,85 @@ DEVI void fft_untangle(const DevPlan &P, const float2 *Z, float2 *out, const flo
     __syncthreads();
 }
 
+// The same transform with the length and the radix sequence known at compile time (frame lengths
+// that get their own instantiation of k_compress): identical arithmetic, operation for operation, but
+// strides, trip counts and the t / stride split are constants.
+template <int W, int M, int SC, int R, int ST>
+DEVI void fft_stage_fixed(const float2 *X, float2 *Y, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    constexpr uint32_t nb = M / R, m = (M / ST) / R, sm = ST * m;
+    for (uint32_t t = threadIdx.x; t < nb; t += T) {
+        const uint32_t p = t / ST, q = t - p * ST;
+        const uint32_t ib = t, ob = q + ST * (R * p), tb = p * ST * SC;
+        if (R == 4) {
+            const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
+            const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+            const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+            const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+            const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+            const float2 t3 = make_float2(d.y, -d.x);
+            Y[ob] = make_float2(t0.x + t2.x, t0.y + t2.y);
+            Y[ob + ST] = cmul_conj_tw(make_float2(t1.x + t3.x, t1.y + t3.y), tw[tb]);
+            Y[ob + 2 * ST] = cmul_conj_tw(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * tb]);
+            Y[ob + 3 * ST] = cmul_conj_tw(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * tb]);
+        } else if (R == 2) {
+            const float2 a0 = X[ib], a1 = X[ib + sm];
+            Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
+            Y[ob + ST] = cmul_conj_tw(make_float2(a0.x - a1.x, a0.y - a1.y), tw[tb]);
+        } else {
+            const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm];
+            const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+            const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+            const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+            const float h = 0.8660254037844386f;
+            const float2 t3 = make_float2(h * d.y, -h * d.x);
+            Y[ob] = make_float2(a0.x + t1.x, a0.y + t1.y);
+            Y[ob + ST] = cmul_conj_tw(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
+            Y[ob + 2 * ST] = cmul_conj_tw(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
+        }
+    }
+    __syncthreads();
+}
+// n = 256: L = 288, M = 144 = 4 * 4 * 3 * 3 (the host's radix order: 4s, then 2s, then 3s)
+template <int W>
+DEVI float2 *fft_forward_144(float2 *X, float2 *Y, const float2 *tw)
+{
+    fft_stage_fixed<W, 144, 2, 4, 1>(X, Y, tw);
+    fft_stage_fixed<W, 144, 2, 4, 4>(Y, X, tw);
+    fft_stage_fixed<W, 144, 2, 3, 16>(X, Y, tw);
+    fft_stage_fixed<W, 144, 2, 3, 48>(Y, X, tw);
+    return X;
+}
+template <int W, int M>
+DEVI void fft_untangle_fixed(const float2 *Z, float2 *out, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+#pragma unroll
+    for (uint32_t k0 = 0; k0 <= M; k0 += T) {
+        const uint32_t k = k0 + threadIdx.x;
+        if (k <= M) {
+            const float2 zk = Z[k == M ? 0 : k];
+            const float2 zm = Z[k == 0 ? 0 : M - k];
+            const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 t = cmul_conj_tw(make_float2(b.y, -b.x), tw[k]);
+            out[k] = make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+        }
+    }
+    __syncthreads();
+}
+
+constexpr uint32_t cx_next_size(uint32_t n)  // utils/mod.rs:32-49 at compile time
+{
+    for (uint32_t v = n + 1;; ++v) {
+        uint32_t r = v;
+        while (r % 2 == 0) r /= 2;
+        while (r % 3 == 0) r /= 3;
+        if (r == 1) return v;
+    }
+}
+
 // O(n^2) transform for n < 128 (any n, primes included).  f64 accumulation, f32 result.
 template <int W>
 DEVI void dft_direct(const DevPlan &P, const double *xs, float2 *out, const float2 *tw)
@@ -171,8 +250,10 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // --------------------------------------------------------------------------------------------
 // the frame kernel
 // --------------------------------------------------------------------------------------------
-// one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs)
-template <int W, int SPL, bool IDW>
+// one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs).
+// FN != 0: every frame of the launch has FN samples (FN >= 128, even transform length) and the frame
+// geometry is folded at compile time; FN == 0 reads it from the per-length table.
+template <int W, int SPL, bool IDW, int FN>
 __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void k_compress(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
@@ -197,7 +278,13 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         fr = frames[fid];
     }
     const DevPlan &P = plans[fr.plan];
-    const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins;
+    constexpr bool FIX = FN != 0;
+    constexpr uint32_t cL = FIX ? cx_next_size(FIX ? FN : 1) : 0, cmf = (3 >= FN / 100) ? 3 : FN / 100;
+    static_assert(!FIX || (FN >= 128 && cL % 2 == 0 && cL <= 64 * W * SPL), "fixed-length instantiation");
+    const uint32_t n = FIX ? FN : P.n, L = FIX ? cL : P.L, pre = FIX ? (cL - FN) / 2 : P.pre;
+    const uint32_t bins = FIX ? cL / 2 + 1 : P.bins;
+    const uint32_t mf = FIX ? cmf : P.mf;
+    const uint32_t dk1 = FIX ? (cmf / 2 > 1 ? cmf / 2 : 1) : P.dk1, dk2 = FIX ? (cmf / 10 > 1 ? cmf / 10 : 1) : P.dk2;
 
     double *xs = (double *)(smem + P.o_xs);
     float2 *tw = (float2 *)(smem + P.o_tw);
@@ -538,7 +625,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
     bool poly_first = false;
     if (prune && run_fft && run_poly && smax != smin) {
-        poly_first = poly_payload_size(P.pstep[0], P.pK[0]) < 1 + 1 + 9 * min(P.mf, bins) + 8;
+        poly_first = poly_payload_size(P.pstep[0], P.pK[0]) < 1 + 1 + 9 * min(mf, bins) + 8;
     }
     auto eval_poly = [&]() {
         // =========================================================================================
@@ -733,7 +820,19 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
             }
             float2 *spec;
-            if (P.direct) {
+            if (FIX) {
+                float *Af = (float *)A;
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) Af[j] = (float)g[m];
+                }
+                __syncthreads();
+                static_assert(!FIX || cL == 288, "add the stage list of the new fixed length");
+                float2 *Z = fft_forward_144<W>(A, B, tw);
+                spec = (Z == A) ? B : A;
+                fft_untangle_fixed<W, FIX ? cL / 2 : 2>(Z, spec, tw);
+            } else if (P.direct) {
                 __syncthreads();
                 dft_direct<W>(P, xs, A, tw);
                 spec = A;
@@ -807,13 +906,13 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             // min(max()) (a NaN sample still poisons the sum through o - g); otherwise compare-select
             const bool fast_clamp = fabsf(mxf) < 1e30f && fabsf(mnf) < 1e30f;
             const double invL = 1.0 / Ld;
-            const uint32_t magicL = P.magicL;
+            const uint32_t magicL = FIX ? (uint32_t)(0x100000000ull / (FIX ? cL : 1)) + 1u : P.magicL;
             uint32_t used = 0, jump = 0, big = 0;
             double cur = prm.max_err + 1.0;
             // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
             // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
             while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
-                const uint32_t K = min(P.mf + jump, Z);
+                const uint32_t K = min(mf + jump, Z);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
                 for (; used < K; ++used) {
@@ -892,8 +991,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 }
                 s = block_sum_f64<W>(s, red, parity);
                 cur = s * invL;  // mean over the L padded samples (utils/error.rs:115); 1/L rounded once
-                if (fft_trips <= 17) jump += P.dk1;       // fft.rs:348-352
-                else if (fft_trips <= 22) jump += P.dk2;
+                if (fft_trips <= 17) jump += dk1;       // fft.rs:348-352
+                else if (fft_trips <= 22) jump += dk2;
                 else break;
             }
             fft_err = cur;
@@ -1307,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
 // --------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------
-template <int W, int SPL, bool IDW>
+template <int W, int SPL, bool IDW, int FN>
 static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
@@ -1315,7 +1414,7 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
                                hipEvent_t ev0, hipEvent_t ev1)
 {
     if (count == 0) return hipSuccess;
-    auto kern = k_compress<W, SPL, IDW>;
+    auto kern = k_compress<W, SPL, IDW, FN>;
     if (const char *pad = getenv("ATSC_DEBUG_LDS_PAD")) lds += (uint32_t)atoi(pad);  // occupancy experiments only
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
@@ -1337,8 +1436,12 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
                                hipEvent_t ev0, hipEvent_t ev1)
 {
     if (prm.mode == ATSC_IDW)
-        return launch_class2<W, SPL, true>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
-    return launch_class2<W, SPL, false>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    // a uniform launch of 256-sample frames (a size the reference chunker emits, and BASELINE's
+    // framing) takes the instantiation with the frame geometry folded in
+    if (W == 1 && SPL == 5 && uni.enabled && uni.n == 256)
+        return launch_class2<1, 5, false, (W == 1 && SPL == 5) ? 256 : 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    return launch_class2<W, SPL, false, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
 }
 
 hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const double *samples,

@@ -677,3 +677,29 @@ def test_rle_few_runs_fuzz(ctx, A, oracle, seed):
             # saturates integer-valued samples beyond i32; the decode has to equal the oracle's
             ref = oracle.decompress_data(A.bro_prefix(len(off) - 1) + s["records"])
             assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
+
+
+def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch):
+    """Uniform batches of 256-sample frames run k_compress<1,5,false,256> (geometry folded at compile
+    time); ATSC_NO_UNIFORM forces the table-driven instantiation.  Same bytes, same errors."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    nf = 4096
+    x = H.synth_series(11, nf * 256, block=8192)
+    off = H.frame_offsets(len(x), 256)
+    d_x = torch.from_numpy(x).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("ATSC_NO_UNIFORM", "1")
+        plan = ctx.plan(off)
+        for me in (ME5, ME1):
+            o = plan.alloc_outputs(torch, dev)
+            plan.compress(d_x, o, A.AUTO, True, me, 0, stream)
+            torch.cuda.synchronize()
+            total = int(o["rec_off"][-1].item())
+            got.append((o["body"][:total].cpu().numpy().tobytes(), o["err"].cpu().numpy().copy()))
+    assert got[0][0] == got[2][0] and got[1][0] == got[3][0]
+    assert np.array_equal(got[0][1], got[2][1], equal_nan=True) and np.array_equal(got[1][1], got[3][1], equal_nan=True)
