@@ -283,18 +283,11 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
         p.o_aux = o; o += align16(4 * (n + 2));
     } else {
-        // Compressor: the frames in flight per CU are bounded by this footprint (160 KB / lds_bytes),
-        // so nothing is kept that two phases can share.  One-wavefront classes reduce through DPP
-        // and need `red` only for the scan total; `aux` (u32[n+2]) lives in the upper part of the
-        // twiddle region, which holds twiddles only from the forward FFT to the end of its ladder
-        // and the RLE group table u32[n] below `aux` otherwise.
         const int c = class_of(n, p.L);
-        p.o_red = o; o += (c >= 0 && c <= 2) ? 16 : 384;
-        p.o_xs = o; o += align16(8 * n);
-        p.o_tw = o; o += align16(std::max(8 * p.L, 4 * n + 4 * (n + 2)));
-        p.o_aux = p.o_tw + 4 * n;
-        p.o_ab = o; o += p.ab_bytes;
-        p.o_sel = o; o += align16(12 * std::max(p.kcap, 1u));
+        const EncLds e = enc_lds(n, p.L, p.direct ? p.bins : p.M, p.direct != 0, p.kcap, c >= 0 && c <= 2);
+        p.o_red = e.o_red; p.o_xs = e.o_xs; p.o_tw = e.o_tw; p.o_aux = e.o_aux; p.o_ab = e.o_ab;
+        p.ab_half = e.ab_half; p.ab_bytes = e.ab_bytes; p.o_sel = e.o_sel;
+        o = e.total;
     }
     p.lds_bytes = o;
     auto it = tw_by_L.find(p.L);

@@ -42,6 +42,43 @@ struct DevPlan {
     uint32_t pgap[23];    // (n - 1) - (K - 2) * step: length of the last segment
 };
 
+// LDS carve-up of one compressor frame (bytes).  One definition for the host (DevPlan::o_*) and for
+// the kernel instantiations that know the frame length at compile time.  Nothing is kept that two
+// phases can share -- the footprint bounds the frames in flight per CU (160 KB / total):
+//   red  reduction scratch (one-wavefront classes reduce through DPP: 16 B for the scan total)
+//   xs   the frame, f64[n]
+//   tw   twiddles float2[L] from the forward FFT to the end of its ladder; otherwise the RLE group
+//        table u32[n] and, above it, aux u32[n + 2]
+//   ab   two FFT work buffers of ab_half bytes (8 B per complex point, +8 so the second one can hold
+//        M + 1 bins); later spline tables, RLE run records (>= 8n + 64 bytes) and the RLE hash table
+//   sel  admitted bins, 12 B each
+struct EncLds {
+    uint32_t o_red, o_xs, o_tw, o_aux, o_ab, ab_half, ab_bytes, o_sel, total;
+};
+#if defined(__HIPCC__)
+#define ATSC_HD __host__ __device__
+#else
+#define ATSC_HD
+#endif
+ATSC_HD constexpr uint32_t enc_align16(uint32_t v) { return (v + 15u) & ~15u; }
+ATSC_HD constexpr uint32_t enc_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+ATSC_HD constexpr EncLds enc_lds(uint32_t n, uint32_t L, uint32_t fft_points /* bins if direct, else M */,
+                                 bool direct, uint32_t kcap, bool one_wave)
+{
+    EncLds e{};
+    e.ab_half = enc_align16(direct ? 8 * fft_points : 8 * fft_points + 8);
+    e.ab_bytes = enc_max(2 * e.ab_half, enc_align16(8 * n + 64));
+    uint32_t o = 0;
+    e.o_red = o; o += one_wave ? 16 : 384;
+    e.o_xs = o; o += enc_align16(8 * n);
+    e.o_tw = o; o += enc_align16(enc_max(8 * L, 4 * n + 4 * (n + 2)));
+    e.o_aux = e.o_tw + 4 * n;
+    e.o_ab = o; o += e.ab_bytes;
+    e.o_sel = o; o += enc_align16(12 * enc_max(kcap, 1u));
+    e.total = o;
+    return e;
+}
+
 struct DevFrame {
     uint64_t sample_off;
     uint64_t slot_off;  // byte offset of the frame's payload slot in the scratch arena

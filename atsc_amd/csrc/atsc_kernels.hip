@@ -284,16 +284,23 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     const uint32_t n = FIX ? FN : P.n, L = FIX ? cL : P.L, pre = FIX ? (cL - FN) / 2 : P.pre;
     const uint32_t bins = FIX ? cL / 2 + 1 : P.bins;
     const uint32_t mf = FIX ? cmf : P.mf;
-    const uint32_t dk1 = FIX ? (cmf / 2 > 1 ? cmf / 2 : 1) : P.dk1, dk2 = FIX ? (cmf / 10 > 1 ? cmf / 10 : 1) : P.dk2;
+    constexpr uint32_t cdk1 = cmf / 2 > 1 ? cmf / 2 : 1, cdk2 = cmf / 10 > 1 ? cmf / 10 : 1;
+    constexpr uint32_t ckcap = (cL / 2 + 1 < cmf + 17 * cdk1 + 5 * cdk2) ? cL / 2 + 1 : cmf + 17 * cdk1 + 5 * cdk2;
+    const uint32_t dk1 = FIX ? cdk1 : P.dk1, dk2 = FIX ? cdk2 : P.dk2;
+    // LDS carve-up: the host's layout function evaluated at compile time for a fixed length
+    constexpr EncLds lay = enc_lds(FIX ? FN : 1, FIX ? cL : 1, FIX ? cL / 2 : 1, false, ckcap, W == 1);
+    const uint32_t o_xs = FIX ? lay.o_xs : P.o_xs, o_tw = FIX ? lay.o_tw : P.o_tw, o_ab = FIX ? lay.o_ab : P.o_ab;
+    const uint32_t ab_half = FIX ? lay.ab_half : P.ab_half, ab_bytes = FIX ? lay.ab_bytes : P.ab_bytes;
+    const uint32_t o_sel = FIX ? lay.o_sel : P.o_sel, o_aux = FIX ? lay.o_aux : P.o_aux, o_red = FIX ? lay.o_red : P.o_red;
 
-    double *xs = (double *)(smem + P.o_xs);
-    float2 *tw = (float2 *)(smem + P.o_tw);
-    unsigned char *AB = smem + P.o_ab;
+    double *xs = (double *)(smem + o_xs);
+    float2 *tw = (float2 *)(smem + o_tw);
+    unsigned char *AB = smem + o_ab;
     float2 *A = (float2 *)AB;
-    float2 *B = (float2 *)(AB + P.ab_half);
-    Sel *sel = (Sel *)(smem + P.o_sel);
-    uint32_t *aux = (uint32_t *)(smem + P.o_aux);
-    double *red = (double *)(smem + P.o_red);
+    float2 *B = (float2 *)(AB + ab_half);
+    Sel *sel = (Sel *)(smem + o_sel);
+    uint32_t *aux = (uint32_t *)(smem + o_aux);
+    double *red = (double *)(smem + o_red);
     uint32_t *wsum = (W == 1) ? (uint32_t *)red : (uint32_t *)(red + 32);  // W == 1: `red` is 16 bytes
     int parity = 0;
 
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         rle_ib = pk >> 13;
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
         rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * (minval + 1);
-        if (W == 1 && rle_R <= 16 && P.ab_bytes >= 128) {
+        if (W == 1 && rle_R <= 16 && ab_bytes >= 128) {
             rle_small_build();
             const RleLane g = rle_small_group();
             rle_D = g.D;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         } else if (mode == ATSC_RLE) {
             rle_sort_and_group(rrec_std, rhp_std, rph_std);
             rle_sorted = true;
-        } else if (rle_R <= 64 && 12 * rle_R + 16 <= P.ab_bytes) {
+        } else if (rle_R <= 64 && 12 * rle_R + 16 <= ab_bytes) {
             // few runs: size it now (AB is still free), so that it can stop the ladders early
             uint32_t *e_rec = (uint32_t *)AB;
             rle_sort_and_group(e_rec, e_rec + rle_R, e_rec + 2 * rle_R + 1);
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         const double stepd = (double)step, gapLd = (double)gapL;
                         const double ry = P.pry[ti], ryL = P.pryL[ti];
                         const uint32_t mm_bytes = (16 * K + 15) & ~15u;
-                        const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= P.ab_bytes);
+                        const bool use_tab = (K >= 6) && (mm_bytes + 32 * step <= ab_bytes);
                         double4 *hb = (double4 *)(AB + mm_bytes);  // basis (h00, h10, h01, h11) per offset r
                         __syncthreads();
                         for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             // Exact size without sorting: count the distinct run values and their multiplicities
             // in an LDS hash table (AB is free: ab_bytes / 4 >= 2n slots of run-end indices).
             uint32_t *tab = (uint32_t *)AB;
-            const uint32_t H = P.ab_bytes >> 2;
+            const uint32_t H = ab_bytes >> 2;
             __syncthreads();
             for (uint32_t i = tid; i < H; i += T) tab[i] = 0xFFFFFFFFu;
             for (uint32_t j = tid; j < n; j += T) aux[j] = 0;
