@@ -194,6 +194,18 @@ extern "C" uint64_t atsc_payload_bound_bytes(uint64_t n)
     return 32 + (n > 65535 ? 17 : 14) * n;
 }
 
+// Large-frame transform of a plan: two LDS-tiled passes when the batch has more large frames than
+// the GPU has CUs to give them (fewer bytes through L2: 15.7 vs 14.3 Gsamples/s at 256+ frames), the
+// stage-by-stage form when every frame has a CU to itself and latency is what counts (6.8 vs 6.0
+// Gsamples/s at 80 frames).  ATSC_LARGE_FFT=tiled|stages overrides (tests, experiments).
+static void choose_large_fft(std::vector<DevPlan> &plans, uint32_t n_large_frames)
+{
+    bool tiled = n_large_frames > 128;
+    if (const char *e = getenv("ATSC_LARGE_FFT")) tiled = strcmp(e, "tiled") == 0;
+    if (!tiled)
+        for (DevPlan &p : plans) p.f4_m1 = p.f4_m2 = 0;
+}
+
 static int class_of(uint32_t n, uint32_t L)
 {
     if (L <= 128) return 0;                               // <1,2>
@@ -266,6 +278,12 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
             if (t + 1 <= 17) jump += dj1;
             else if (t + 1 <= 22) jump += dj2;
         }
+    }
+    p.f4_m1 = p.f4_m2 = 0;
+    if (!p.direct && p.M >= 64) {
+        uint32_t d = (uint32_t)std::sqrt((double)p.M);
+        while (d > 1 && p.M % d != 0) --d;
+        if (d > 1 && p.M / d <= 480) { p.f4_m1 = d; p.f4_m2 = p.M / d; }
     }
     p.p2bins = pow2_ge(p.bins);
     p.p2n = pow2_ge(n);
@@ -553,6 +571,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
             u.plan = f0.plan;
         }
     }
+    choose_large_fft(p->tabs.plans, p->class_count[CLASS_LARGE]);
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_plan_destroy(p); return rc; }
     const uint32_t nb = (uint32_t)((n_frames + 1023) / 1024);
@@ -628,6 +647,7 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
         for (int c = 0; c < N_CLASSES; ++c) { t->class_first[c] = acc; acc += t->class_count[c]; }
         std::vector<uint32_t> cur(t->class_first);
         for (size_t i = 0; i < sel.size(); ++i) ids[cur[cls[i]]++] = sel[i];
+        choose_large_fft(t->tabs.plans, t->class_count[CLASS_LARGE]);
         int rc = upload_tables(ctx, t->tabs);
         if (rc) { free_sub(t); return rc; }
 #define TCHK(call)                                                                      \
@@ -1140,6 +1160,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         std::vector<uint32_t> cur(p->class_first);
         for (size_t f = 0; f < frames.size(); ++f) ids[cur[cls[f]]++] = (uint32_t)f;
     }
+    choose_large_fft(p->tabs.plans, p->class_count[CLASS_LARGE]);
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_dplan_destroy(p); return rc; }
 #define PCHK(call)                                                                      \

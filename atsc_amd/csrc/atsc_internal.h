@@ -25,6 +25,8 @@ struct DevPlan {
     uint32_t p2bins;   // power of two >= bins (sort network size)
     uint32_t p2n;      // power of two >= n
     uint32_t magicL;   // floor(2^32 / L) + 1 (L >= 2): x mod L without a divide
+    uint32_t f4_m1, f4_m2;  // M = f4_m1 * f4_m2, f4_m1 <= f4_m2 as close as the factors allow: the
+                            // large tier transforms in two LDS-tiled passes (0: keep the stage-by-stage form)
     uint32_t lds_bytes;
     // LDS carve offsets (bytes, 16-aligned).  AB = two FFT work buffers of ab_half bytes each,
     // later reused for spline tables, RLE run records and the RLE hash table.

@@ -30,7 +30,66 @@ DEVI float2 cmulp(float2 v, float2 w)  // v * (w.x + i w.y)
     return make_float2(v.x * w.x - v.y * w.y, v.y * w.x + v.x * w.y);
 }
 
-// Stockham stages over global buffers (same butterflies as fft_forward in atsc_kernels.hip).
+// Stockham stages over global buffers (same butterflies as fft_forward in atsc_kernels.hip).  One
+// workgroup walks a frame, so a stage is bound by memory latency, not bandwidth: the radix switch
+// sits outside the butterfly loop and every thread keeps U butterflies in flight (all their loads are
+// issued before the first result is needed).
+template <int R, int U>
+DEVI void fft_stage_g(const float2 *__restrict__ X, float2 *__restrict__ Y, const float2 *__restrict__ tw,
+                      uint32_t nb, uint32_t st, uint32_t sm, uint32_t sc, uint32_t magic)
+{
+    for (uint32_t t0 = threadIdx.x; t0 < nb; t0 += LT * U) {
+        float2 a[U][R], w[U][R];
+        uint32_t ob[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u * LT;
+            live[u] = t < nb;
+            const uint32_t tt = live[u] ? t : 0;
+            const uint32_t p = (st == 1) ? tt : __umulhi(tt, magic);
+            const uint32_t q = tt - p * st;
+            const uint32_t ib = q + st * p;
+            ob[u] = q + st * (R * p);
+            const uint32_t tb = p * st * sc;
+#pragma unroll
+            for (int j = 0; j < R; ++j) a[u][j] = X[ib + j * sm];
+#pragma unroll
+            for (int j = 1; j < R; ++j) w[u][j] = tw[j * tb];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const uint32_t o = ob[u];
+            if (R == 4) {
+                const float2 a0 = a[u][0], a1 = a[u][1], a2 = a[u][2], a3 = a[u][3 % R];
+                const float2 t0v = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+                const float2 t3 = make_float2(d.y, -d.x);
+                Y[o] = make_float2(t0v.x + t2.x, t0v.y + t2.y);
+                Y[o + st] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w[u][1]);
+                Y[o + 2 * st] = cmulc(make_float2(t0v.x - t2.x, t0v.y - t2.y), w[u][2 % R]);
+                Y[o + 3 * st] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w[u][3 % R]);
+            } else if (R == 2) {
+                const float2 a0 = a[u][0], a1 = a[u][1];
+                Y[o] = make_float2(a0.x + a1.x, a0.y + a1.y);
+                Y[o + st] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), w[u][1]);
+            } else {
+                const float2 a0 = a[u][0], a1 = a[u][1], a2 = a[u][2 % R];
+                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                const float h = 0.8660254037844386f;
+                const float2 t3 = make_float2(h * d.y, -h * d.x);
+                Y[o] = make_float2(a0.x + t1.x, a0.y + t1.y);
+                Y[o + st] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), w[u][1]);
+                Y[o + 2 * st] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), w[u][2 % R]);
+            }
+        }
+    }
+}
 DEVI float2 *fft_forward_g(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw)
 {
     const uint32_t M = P.M, sc = P.sc;
@@ -41,39 +100,9 @@ DEVI float2 *fft_forward_g(const DevPlan &P, float2 *X, float2 *Y, const float2 
         const uint32_t nb = M / r;
         const uint32_t magic = P.stmagic[s];
         const uint32_t sm = st * m;
-        for (uint32_t t = threadIdx.x; t < nb; t += LT) {
-            const uint32_t p = (st == 1) ? t : __umulhi(t, magic);
-            const uint32_t q = t - p * st;
-            const uint32_t ib = q + st * p;
-            const uint32_t ob = q + st * (r * p);
-            const uint32_t tb = p * st * sc;
-            if (r == 4) {
-                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
-                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
-                const float2 t3 = make_float2(d.y, -d.x);
-                Y[ob] = make_float2(t0.x + t2.x, t0.y + t2.y);
-                Y[ob + st] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), tw[tb]);
-                Y[ob + 2 * st] = cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * tb]);
-                Y[ob + 3 * st] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * tb]);
-            } else if (r == 2) {
-                const float2 a0 = X[ib], a1 = X[ib + sm];
-                Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
-                Y[ob + st] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), tw[tb]);
-            } else {
-                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm];
-                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
-                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
-                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
-                const float h = 0.8660254037844386f;
-                const float2 t3 = make_float2(h * d.y, -h * d.x);
-                Y[ob] = make_float2(a0.x + t1.x, a0.y + t1.y);
-                Y[ob + st] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
-                Y[ob + 2 * st] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
-            }
-        }
+        if (r == 4) fft_stage_g<4, 4>(X, Y, tw, nb, st, sm, sc, magic);
+        else if (r == 2) fft_stage_g<2, 4>(X, Y, tw, nb, st, sm, sc, magic);
+        else fft_stage_g<3, 4>(X, Y, tw, nb, st, sm, sc, magic);
         __syncthreads();
         float2 *tmp = X; X = Y; Y = tmp;
         ncur = m;
@@ -82,10 +111,131 @@ DEVI float2 *fft_forward_g(const DevPlan &P, float2 *X, float2 *Y, const float2 
     return X;
 }
 
+// --------------------------------------------------------------------------------------------
+// The same transform in two LDS-tiled passes, M = M1 * M2 (n = M2 n1 + n2, k = k1 + M1 k2):
+//   W_M^{nk} = W_M1^{n1 k1} . W_M^{n2 k1} . W_M2^{n2 k2}
+//   pass 1  FB columns n2 at a time: x[M2 n1 + n2] -> LDS, FB transforms of length M1 along n1,
+//           times W_M^{n2 k1}, out to a[k1 M2 + n2]
+//   pass 2  FB rows k1 at a time: a[k1 M2 + .] -> LDS, FB transforms of length M2 along n2, out to
+//           X[k1 + M1 k2]
+// Global memory is touched in runs of FB * 8 = 128 bytes or whole rows, twice in and twice out,
+// instead of once per radix stage with 8-byte scatters; the butterflies run on LDS.
+// --------------------------------------------------------------------------------------------
+constexpr uint32_t FB = 16;            // sequences per LDS tile
+constexpr uint32_t F4_MAX = 480;       // longest sub-transform the tile buffers hold
+constexpr uint32_t F4_TILE = FB * (F4_MAX + 1);  // float2 per tile buffer
+
+// Stockham over `nseq` sequences of length N held in LDS, element (i, c) at i * si + c * sq.
+// CF: consecutive work items walk the sequences first (si = FB, sq = 1), else the butterflies first.
+template <bool CF>
+DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_t nseq, uint32_t si, uint32_t sq)
+{
+    uint32_t ncur = N, st = 1;
+    while (ncur > 1) {
+        const uint32_t r = (ncur % 4 == 0) ? 4u : (ncur % 2 == 0) ? 2u : 3u;
+        const uint32_t m = ncur / r, nbf = N / r, sm = st * m;
+        const uint32_t mg_st = st > 1 ? (uint32_t)(0x100000000ull / st) + 1u : 0u;
+        const uint32_t mg_nb = nbf > 1 ? (uint32_t)(0x100000000ull / nbf) + 1u : 0u;
+        const uint32_t total = CF ? nbf * FB : nbf * nseq;
+        for (uint32_t w = threadIdx.x; w < total; w += LT) {
+            uint32_t b, c;
+            if (CF) { c = w & (FB - 1); b = w >> 4; if (c >= nseq) continue; }
+            else { c = nbf > 1 ? __umulhi(w, mg_nb) : w; b = w - c * nbf; }
+            const uint32_t p = st > 1 ? __umulhi(b, mg_st) : b;
+            const uint32_t q = b - p * st;
+            const float2 *x = T + (q + st * p) * si + c * sq;
+            float2 *y = U + (q + st * (r * p)) * si + c * sq;
+            const uint32_t e = p * st;  // W_N^{e k}
+            if (r == 4) {
+                const float2 a0 = x[0], a1 = x[sm * si], a2 = x[2 * sm * si], a3 = x[3 * sm * si];
+                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+                const float2 t3 = make_float2(d.y, -d.x);
+                y[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                y[st * si] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), wN[e]);
+                y[2 * st * si] = cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), wN[2 * e]);
+                y[3 * st * si] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), wN[3 * e]);
+            } else if (r == 2) {
+                const float2 a0 = x[0], a1 = x[sm * si];
+                y[0] = make_float2(a0.x + a1.x, a0.y + a1.y);
+                y[st * si] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), wN[e]);
+            } else {
+                const float2 a0 = x[0], a1 = x[sm * si], a2 = x[2 * sm * si];
+                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                const float h = 0.8660254037844386f;
+                const float2 t3 = make_float2(h * d.y, -h * d.x);
+                y[0] = make_float2(a0.x + t1.x, a0.y + t1.y);
+                y[st * si] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), wN[e]);
+                y[2 * st * si] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), wN[2 * e]);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = T; T = U; U = tmp;
+        ncur = m;
+        st *= r;
+    }
+    return T;
+}
+
+// Forward transform of X (length P.M) through the scratch buffer Y; the result lands back in X.
+// `lds` = 2 * F4_TILE + 2 * F4_MAX float2 of LDS that nothing else uses meanwhile.
+DEVI float2 *fft_tiled_g(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw, float2 *lds)
+{
+    const uint32_t M1 = P.f4_m1, M2 = P.f4_m2, sc = P.sc;  // sc = L / M
+    float2 *T = lds, *U = lds + F4_TILE, *w1 = lds + 2 * F4_TILE, *w2 = w1 + F4_MAX;
+    for (uint32_t e = threadIdx.x; e < M1; e += LT) w1[e] = tw[e * (M2 * sc)];  // W_M1^e = W_L^{e L / M1}
+    for (uint32_t e = threadIdx.x; e < M2; e += LT) w2[e] = tw[e * (M1 * sc)];
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < M2; c0 += FB) {  // ---- pass 1: columns
+        const uint32_t nseq = min(FB, M2 - c0);
+        for (uint32_t w = threadIdx.x; w < M1 * FB; w += LT) {
+            const uint32_t c = w & (FB - 1), n1 = w >> 4;
+            if (c < nseq) T[n1 * FB + c] = X[M2 * n1 + c0 + c];
+        }
+        __syncthreads();
+        const float2 *R = lds_fft<true>(T, U, w1, M1, nseq, FB, 1);
+        for (uint32_t w = threadIdx.x; w < M1 * FB; w += LT) {
+            const uint32_t c = w & (FB - 1), k1 = w >> 4;
+            if (c < nseq) {
+                const uint32_t n2 = c0 + c;
+                Y[k1 * M2 + n2] = cmulc(R[k1 * FB + c], tw[n2 * k1 * sc]);  // n2 k1 < M: no wrap
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t ld = M2 + 1;  // odd leading dimension keeps the strided tile accesses off one bank
+    const uint32_t mg_m2 = (uint32_t)(0x100000000ull / M2) + 1u;
+    for (uint32_t r0 = 0; r0 < M1; r0 += FB) {  // ---- pass 2: rows
+        const uint32_t nseq = min(FB, M1 - r0);
+        for (uint32_t w = threadIdx.x; w < nseq * M2; w += LT) {
+            const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * M2;
+            T[r * ld + n2] = Y[(r0 + r) * M2 + n2];
+        }
+        __syncthreads();
+        const float2 *R = lds_fft<false>(T, U, w2, M2, nseq, 1, ld);
+        for (uint32_t w = threadIdx.x; w < M2 * FB; w += LT) {
+            const uint32_t r = w & (FB - 1), k2 = w >> 4;
+            if (r < nseq) X[(r0 + r) + M1 * k2] = R[r * ld + k2];
+        }
+        __syncthreads();
+    }
+    return X;
+}
+// the transform the large tier uses: tiled when the plan has a split, stage by stage otherwise
+DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw, float2 *lds)
+{
+    if (P.f4_m1) return fft_tiled_g(P, X, Y, tw, lds);
+    return fft_forward_g(P, X, Y, tw);
+}
+
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -105,6 +255,7 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_tab = o; o += lw_align(8ull * (n + 8));     // RLE hash table, 2n slots
     w.o_rps = o; o += lw_align(4ull * (n + 8));
     w.o_rph = o; o += lw_align(4ull * (n + 8));
+    w.o_spos = o; o += lw_align(4ull * (16384 + 8));  // admission order (bin positions) once sorted: frees the LDS
     w.bytes = o;
     return w;
 }
@@ -192,6 +343,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     uint32_t *tab = (uint32_t *)(ws + lay.o_tab);
     uint32_t *rps = (uint32_t *)(ws + lay.o_rps);
     uint32_t *rph = (uint32_t *)(ws + lay.o_rph);
+    uint32_t *spos = (uint32_t *)(ws + lay.o_spos);
+    float2 *fft_lds = (float2 *)keys;  // the key buffer is idle whenever a transform runs
 
     const double *xs = samples + fr.sample_off;  // read in place (L2 keeps a 1 MB frame)
     const float2 *tw = twpool + P.tw_off;
@@ -293,6 +446,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         if (can_win(size, owner)) { best_size = size; best_owner = owner; }
     };
 
+    if (prm.debug_stop == 1) return;
     // ---- RLE (rle.rs:142-189): bound first; exact right away when there are few runs ----
     uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0, rle_lb = 0xFFFFFFFFu;
     bool rle_sorted = false, rle_pending = false;
@@ -353,6 +507,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         }
     }
 
+    if (prm.debug_stop == 2) return;
     // =========================================================================================
     // FFT candidate (fft.rs:288-362)
     // =========================================================================================
@@ -376,7 +531,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 float *Af = (float *)A;
                 for (uint32_t j = tid; j < L; j += T) Af[j] = (float)gpad(j);
                 __syncthreads();
-                float2 *Z = fft_forward_g(P, A, B, tw);
+                float2 *Z = fft_large(P, A, B, tw, fft_lds);
                 spec = (Z == A) ? B : A;
                 for (uint32_t k = tid; k <= M; k += T) {  // untangle (see fft_untangle)
                     const float2 zk = Z[k == M ? 0 : k];
@@ -390,9 +545,10 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             } else {
                 for (uint32_t j = tid; j < L; j += T) A[j] = make_float2((float)gpad(j), 0.0f);
                 __syncthreads();
-                spec = fft_forward_g(P, A, B, tw);
+                spec = fft_large(P, A, B, tw, fft_lds);
             }
             float2 *work = (spec == A) ? B : A;  // free FFT buffer from here on
+            if (prm.debug_stop == 4) return;
 
             // ---- admission order: the kcap largest norms, descending, ties by position ----
             uint32_t nz = 0;
@@ -478,9 +634,14 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 nkeys = above + need_ties;
                 __syncthreads();
             }
+            if (prm.debug_stop == 3) return;
             uint32_t p2 = 1;
             while (p2 < nkeys) p2 <<= 1;
             block_sort<W, true>(keys, nullptr, nkeys, p2);
+            // the order goes to the workspace: the ladder's transforms take the LDS over
+            for (uint32_t i = tid; i < nkeys; i += T) spos[i] = (uint32_t)(keys[i] & 0xffffffffu);
+            __syncthreads();
+            if (prm.debug_stop == 5) return;
 
             // ---- ladder ----
             const bool wraps = bins > 65536;
@@ -504,7 +665,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 // mirrored back by get_mirrored_freqs -- at pos - 65536, later entries overwriting
                 // earlier ones.  own[] keeps, per stored position, the latest admission index.
                 for (uint32_t i = used + tid; i < K; i += T) {
-                    const uint32_t pos = (uint32_t)(keys[i] & 0xffffffffu);
+                    const uint32_t pos = spos[i];
                     const float2 z = spec[pos];
                     sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
                     if (wraps) atomicMax(&own[pos & 0xffffu], i + 1);
@@ -537,7 +698,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         work[k] = make_float2(e.x - o.y, -(e.y + o.x));
                     }
                     __syncthreads();
-                    F = fft_forward_g(P, work, Cb, tw);
+                    F = fft_large(P, work, Cb, tw, fft_lds);
                 } else {
                     for (uint32_t k = tid; k < L; k += T) {
                         float2 v = make_float2(0.0f, 0.0f);
@@ -546,7 +707,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         work[k] = make_float2(v.x, -v.y);  // conj for inverse-by-forward
                     }
                     __syncthreads();
-                    F = fft_forward_g(P, work, Cb, tw);
+                    F = fft_large(P, work, Cb, tw, fft_lds);
                 }
                 // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
                 double s = 0.0;
@@ -585,6 +746,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         dg.fft_err = fft_err;
     }
 
+    if (prm.debug_stop == 6) return;
     // =========================================================================================
     // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
     // interpolation (polynomial.rs:375-393)
@@ -742,6 +904,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
     }
 
+    if (prm.debug_stop == 7) return;
     // ---- RLE with many runs: exact size (hash of run values) only if its bound can still win ----
     if (run_rle && rle_pending) {
         if (!prune || can_win(rle_lb, 2)) {
@@ -1139,7 +1302,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             }
         }
         __syncthreads();
-        F = fft_forward_g(P, A, Cb, tw);
+        F = fft_large(P, A, Cb, tw, (float2 *)(smem + 256));
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
         for (uint32_t i = tid; i < n; i += T) {
@@ -1181,9 +1344,14 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
                                    uint32_t ws_slots, hipStream_t s)
 {
+    // 256 B of header scratch + the tile buffers of the LDS-tiled inverse transform
+    const uint32_t lds = 256 + (2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2);
+    hipError_t ea = hipFuncSetAttribute((const void *)k_decompress_large,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
-        hipLaunchKernelGGL(k_decompress_large, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
+        hipLaunchKernelGGL(k_decompress_large, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
                            body, out, status, ws, ws_stride);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

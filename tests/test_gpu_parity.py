@@ -703,3 +703,32 @@ def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch):
             got.append((o["body"][:total].cpu().numpy().tobytes(), o["err"].cpu().numpy().copy()))
     assert got[0][0] == got[2][0] and got[1][0] == got[3][0]
     assert np.array_equal(got[0][1], got[2][1], equal_nan=True) and np.array_equal(got[1][1], got[3][1], equal_nan=True)
+
+
+@pytest.mark.parametrize("form", ["tiled", "stages"])
+def test_large_frames_both_transform_forms(ctx, A, oracle, monkeypatch, form):
+    """The large tier picks its transform by batch size (LDS-tiled two-pass for many frames, stage by
+    stage for few); both forms, forced through ATSC_LARGE_FFT, meet the same parity bars, encode and decode."""
+    monkeypatch.setenv("ATSC_LARGE_FFT", form)
+    sizes = [4097, 6500, 8192, 20000, 59000, 131072]   # 6500, 59000 -> odd transform lengths 3^8, 3^10
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in ((0, 1) if n > 50000 else (0, 1, 2, 3)):
+            xs.append(H.synth_series(950 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME5)
+    _log(P.assert_summary(s, len(off) - 1, "large frames, %s transform, codecs %s" % (form, s["codecs"])))
+    s = P.compare_batch(oracle, ctx, x, off, A.FFT, True, ME1)
+    _log(P.assert_summary(s, len(off) - 1, "large frames, %s transform, forced fft e=1%%" % form))
+    bro, chosen, _ = oracle.stream_compress(x, off, A.FFT, True, ME5, 0)
+    ref = oracle.decompress_data(bro)
+    body_off, _ = A.bro_open(bro)
+    out = ctx.decompress_host(bro[body_off:])
+    for i in range(len(off) - 1):
+        seg = slice(int(off[i]), int(off[i + 1]))
+        n = int(off[i + 1] - off[i])
+        scale = max(np.max(np.abs(ref[seg])), 1e-30)
+        tol = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5
+        assert np.max(np.abs(out[seg] - ref[seg])) <= tol, (form, i)
