@@ -44,40 +44,39 @@ class PipelinedGather:
     """Steady-state gather for a loop that produces one record buffer per step on every rank.
 
     Segment capacity is agreed once (max over ranks of the observed size, plus slack); after that
-    every step issues one asynchronous `gather` of `cap` bytes per rank and one of the 8-byte sizes,
-    with no host synchronisation: the collectives run on the communicator's stream behind the
-    producing kernel, and the producer moves on to the other buffer set (depth 2).  Rank 0 ends up
-    with `world` segments at stride `cap` plus their sizes: the encoded stream is the concatenation of
-    segment r's first sizes[r] bytes, in rank order = frame order."""
+    every step issues ONE asynchronous `gather` of `cap` bytes per rank, with no host synchronisation:
+    the byte count of the step rides in the last 8 bytes of the segment (a device-side copy into the
+    record buffer, which is far larger than `cap`), so the collective count per step is one and the
+    communicator's stream keeps up with the codecs.  The producer moves on to the other buffer set
+    (depth 2).  Rank 0 ends up with `world` segments at stride `cap`: the encoded stream is the
+    concatenation of segment r's first size_r bytes, in rank order = frame order."""
+
+    TAIL = 8  # bytes at the end of every segment that carry the step's byte count (int64)
 
     def __init__(self, dist, torch, rank, world, device, observed_bytes, slack=1.05, depth=2):
         self.dist, self.torch, self.rank, self.world, self.depth = dist, torch, rank, world, depth
         t = torch.tensor([int(observed_bytes)], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        self.cap = (int(int(t.item()) * slack) + 4096 + 15) & ~15
+        self.cap = (int(int(t.item()) * slack) + 4096 + self.TAIL + 15) & ~15
         self.seg = [None] * depth
-        self.sizes = [None] * depth
         self.work = [None] * depth
         if rank == 0:
             for d in range(depth):
                 self.seg[d] = [torch.empty(self.cap, dtype=torch.uint8, device=device) for _ in range(world)]
-                self.sizes[d] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
 
     def before_produce(self, slot):
         """Call before overwriting buffer set `slot`: waits for the gather that last read it."""
         if self.work[slot] is not None:
-            for w in self.work[slot]:
-                w.wait()
+            self.work[slot].wait()
             self.work[slot] = None
 
     def submit(self, slot, body, nbytes_tensor):
-        """body: this rank's uint8 buffer (>= cap bytes); nbytes_tensor: int64[1] on the same device."""
-        d = self.dist
-        w1 = d.gather(body[: self.cap], gather_list=self.seg[slot] if self.rank == 0 else None, dst=0,
-                      async_op=True)
-        w2 = d.gather(nbytes_tensor.reshape(1), gather_list=self.sizes[slot] if self.rank == 0 else None,
-                      dst=0, async_op=True)
-        self.work[slot] = [w1, w2]
+        """body: this rank's uint8 buffer (>= cap bytes, 8-byte aligned); nbytes_tensor: int64[1] on
+        the same device.  The records must end before cap - TAIL (checked by `result`)."""
+        tail = body[self.cap - self.TAIL: self.cap].view(self.torch.int64)
+        tail.copy_(nbytes_tensor.reshape(1))
+        self.work[slot] = self.dist.gather(body[: self.cap], gather_list=self.seg[slot] if self.rank == 0 else None,
+                                           dst=0, async_op=True)
 
     def drain(self):
         for slot in range(self.depth):
@@ -85,6 +84,6 @@ class PipelinedGather:
 
     def result(self, slot):
         """(rank 0, after drain) -> list of byte views in rank order, and their sizes."""
-        sizes = [int(s.item()) for s in self.sizes[slot]]
-        assert all(s <= self.cap for s in sizes), "a segment outgrew the agreed capacity"
+        sizes = [int(self.seg[slot][r][self.cap - self.TAIL:].view(self.torch.int64).item()) for r in range(self.world)]
+        assert all(0 <= s <= self.cap - self.TAIL for s in sizes), "a segment outgrew the agreed capacity"
         return [self.seg[slot][r][: sizes[r]] for r in range(self.world)], sizes
