@@ -152,15 +152,18 @@ DEVI void fft_stage_fixed(const float2 *X, float2 *Y, const float2 *tw)
     }
     __syncthreads();
 }
-// n = 256: L = 288, M = 144 = 4 * 4 * 3 * 3 (the host's radix order: 4s, then 2s, then 3s)
-template <int W>
-DEVI float2 *fft_forward_144(float2 *X, float2 *Y, const float2 *tw)
+// the stage list of the host (build_plan_entry: 4s, then 2s, then 3s) unrolled at compile time,
+// e.g. n = 256: L = 288, M = 144 = 4 * 4 * 3 * 3
+template <int W, int M, int SC, int REM = M, int ST = 1>
+DEVI float2 *fft_forward_fixed(float2 *X, float2 *Y, const float2 *tw)
 {
-    fft_stage_fixed<W, 144, 2, 4, 1>(X, Y, tw);
-    fft_stage_fixed<W, 144, 2, 4, 4>(Y, X, tw);
-    fft_stage_fixed<W, 144, 2, 3, 16>(X, Y, tw);
-    fft_stage_fixed<W, 144, 2, 3, 48>(Y, X, tw);
-    return X;
+    if constexpr (REM == 1) {
+        return X;
+    } else {
+        constexpr int R = (REM % 4 == 0) ? 4 : (REM % 2 == 0) ? 2 : 3;
+        fft_stage_fixed<W, M, SC, R, ST>(X, Y, tw);
+        return fft_forward_fixed<W, M, SC, REM / R, ST * R>(Y, X, tw);
+    }
 }
 template <int W, int M>
 DEVI void fft_untangle_fixed(const float2 *Z, float2 *out, const float2 *tw)
@@ -835,8 +838,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     if (j < L) Af[j] = (float)g[m];
                 }
                 __syncthreads();
-                static_assert(!FIX || cL == 288, "add the stage list of the new fixed length");
-                float2 *Z = fft_forward_144<W>(A, B, tw);
+                float2 *Z = fft_forward_fixed<W, FIX ? cL / 2 : 2, 2>(A, B, tw);
                 spec = (Z == A) ? B : A;
                 fft_untangle_fixed<W, FIX ? cL / 2 : 2>(Z, spec, tw);
             } else if (P.direct) {
@@ -1444,10 +1446,24 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
 {
     if (prm.mode == ATSC_IDW)
         return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
-    // a uniform launch of 256-sample frames (a size the reference chunker emits, and BASELINE's
-    // framing) takes the instantiation with the frame geometry folded in
-    if (W == 1 && SPL == 5 && uni.enabled && uni.n == 256)
-        return launch_class2<1, 5, false, (W == 1 && SPL == 5) ? 256 : 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    // uniform launches of the power-of-two frame lengths the reference chunker emits (256 is also
+    // BASELINE's framing) take the instantiation with the frame geometry folded in; 2048 has an odd
+    // transform length (3^7) and stays table-driven
+    if (uni.enabled) {
+        if constexpr (W == 1 && SPL == 5) {
+            if (uni.n == 256) return launch_class2<1, 5, false, 256>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+            if (uni.n == 128) return launch_class2<1, 5, false, 128>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        }
+        if constexpr (W == 1 && SPL == 9) {
+            if (uni.n == 512) return launch_class2<1, 9, false, 512>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        }
+        if constexpr (W == 4 && SPL == 5) {
+            if (uni.n == 1024) return launch_class2<4, 5, false, 1024>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        }
+        if constexpr (W == 16 && SPL == 5) {
+            if (uni.n == 4096) return launch_class2<16, 5, false, 4096>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        }
+    }
     return launch_class2<W, SPL, false, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
 }
 

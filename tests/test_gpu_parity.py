@@ -679,15 +679,17 @@ def test_rle_few_runs_fuzz(ctx, A, oracle, seed):
             assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
 
 
-def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch):
-    """Uniform batches of 256-sample frames run k_compress<1,5,false,256> (geometry folded at compile
-    time); ATSC_NO_UNIFORM forces the table-driven instantiation.  Same bytes, same errors."""
+@pytest.mark.parametrize("flen", [128, 256, 512, 1024, 4096])
+def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch, flen):
+    """Uniform batches of 128 / 256 / 512 / 1024 / 4096-sample frames run k_compress<.., FN> (geometry
+    and FFT stage list folded at compile time); ATSC_NO_UNIFORM forces the table-driven instantiation.
+    Same bytes, same errors."""
     import torch
 
     dev = torch.device("cuda", 0)
-    nf = 4096
-    x = H.synth_series(11, nf * 256, block=8192)
-    off = H.frame_offsets(len(x), 256)
+    nf = (1 << 20) // flen
+    x = H.synth_series(11, nf * flen, block=8192)
+    off = H.frame_offsets(len(x), flen)
     d_x = torch.from_numpy(x).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
     got = []
