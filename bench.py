@@ -312,7 +312,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_compress<1,5>",
+                "kernel": "k_compress<1,5,false,256>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
