@@ -734,3 +734,44 @@ def test_large_frames_both_transform_forms(ctx, A, oracle, monkeypatch, form):
         scale = max(np.max(np.abs(ref[seg])), 1e-30)
         tol = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5
         assert np.max(np.abs(out[seg] - ref[seg])) <= tol, (form, i)
+
+
+def test_compress_is_graph_capturable(ctx, A):
+    """atsc_compress_plan_dev only enqueues kernels on the caller's stream: it can be captured into a
+    HIP graph and replayed on new data in the same buffers."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    nf, F = 4096, 256
+    off = H.frame_offsets(nf * F, F)
+    plan = ctx.plan(off)
+    d_x = torch.empty(nf * F, dtype=torch.float64, device=dev)
+    outs = plan.alloc_outputs(torch, dev)
+    batches = [torch.from_numpy(H.synth_series(500 + b, nf * F, block=4096)).to(dev) for b in range(3)]
+
+    def fetch():
+        total = int(outs["rec_off"][-1].item())
+        return outs["body"][:total].cpu().numpy().tobytes()
+
+    want = []
+    for b in batches:
+        d_x.copy_(b)
+        plan.compress(d_x, outs, A.AUTO, True, ME5, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want.append(fetch())
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        plan.compress(d_x, outs, A.AUTO, True, ME5, 0, side.cuda_stream)  # warm-up outside the capture
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            plan.compress(d_x, outs, A.AUTO, True, ME5, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i, b in enumerate(batches):
+        d_x.copy_(b)
+        outs["body"].zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert fetch() == want[i], i
