@@ -283,7 +283,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     const DevPlan &P = plans[fr.plan];
     constexpr bool FIX = FN != 0;
     constexpr uint32_t cL = FIX ? cx_next_size(FIX ? FN : 1) : 0, cmf = (3 >= FN / 100) ? 3 : FN / 100;
-    static_assert(!FIX || (FN >= 128 && cL % 2 == 0 && cL <= 64 * W * SPL), "fixed-length instantiation");
+    static_assert(!FIX || (FN >= 128 && cL <= 64 * W * SPL), "fixed-length instantiation");
+    constexpr bool chalf = cL % 2 == 0;              // even L: packed real transform of length L / 2
+    constexpr uint32_t cM = chalf ? cL / 2 : cL;     // points through the Stockham stages
     const uint32_t n = FIX ? FN : P.n, L = FIX ? cL : P.L, pre = FIX ? (cL - FN) / 2 : P.pre;
     const uint32_t bins = FIX ? cL / 2 + 1 : P.bins;
     const uint32_t mf = FIX ? cmf : P.mf;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     constexpr uint32_t ckcap = (cL / 2 + 1 < cmf + 17 * cdk1 + 5 * cdk2) ? cL / 2 + 1 : cmf + 17 * cdk1 + 5 * cdk2;
     const uint32_t dk1 = FIX ? cdk1 : P.dk1, dk2 = FIX ? cdk2 : P.dk2;
     // LDS carve-up: the host's layout function evaluated at compile time for a fixed length
-    constexpr EncLds lay = enc_lds(FIX ? FN : 1, FIX ? cL : 1, FIX ? cL / 2 : 1, false, ckcap, W == 1);
+    constexpr EncLds lay = enc_lds(FIX ? FN : 1, FIX ? cL : 1, FIX ? cM : 1, false, ckcap, W == 1);
     const uint32_t o_xs = FIX ? lay.o_xs : P.o_xs, o_tw = FIX ? lay.o_tw : P.o_tw, o_ab = FIX ? lay.o_ab : P.o_ab;
     const uint32_t ab_half = FIX ? lay.ab_half : P.ab_half, ab_bytes = FIX ? lay.ab_bytes : P.ab_bytes;
     const uint32_t o_sel = FIX ? lay.o_sel : P.o_sel, o_aux = FIX ? lay.o_aux : P.o_aux, o_red = FIX ? lay.o_red : P.o_red;
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
             }
             float2 *spec;
-            if (FIX) {
+            if (FIX && chalf) {
                 float *Af = (float *)A;
 #pragma unroll
                 for (int m = 0; m < SPL; ++m) {
@@ -838,9 +840,17 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     if (j < L) Af[j] = (float)g[m];
                 }
                 __syncthreads();
-                float2 *Z = fft_forward_fixed<W, FIX ? cL / 2 : 2, 2>(A, B, tw);
+                float2 *Z = fft_forward_fixed<W, FIX ? cM : 2, 2>(A, B, tw);
                 spec = (Z == A) ? B : A;
-                fft_untangle_fixed<W, FIX ? cL / 2 : 2>(Z, spec, tw);
+                fft_untangle_fixed<W, FIX ? cM : 2>(Z, spec, tw);
+            } else if (FIX) {  // odd transform length: full complex transform of the real signal
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < L) A[j] = make_float2((float)g[m], 0.0f);
+                }
+                __syncthreads();
+                spec = fft_forward_fixed<W, FIX ? cM : 3, 1>(A, B, tw);
             } else if (P.direct) {
                 __syncthreads();
                 dft_direct<W>(P, xs, A, tw);
@@ -1447,8 +1457,7 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
     if (prm.mode == ATSC_IDW)
         return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     // uniform launches of the power-of-two frame lengths the reference chunker emits (256 is also
-    // BASELINE's framing) take the instantiation with the frame geometry folded in; 2048 has an odd
-    // transform length (3^7) and stays table-driven
+    // BASELINE's framing) take the instantiation with the frame geometry folded in
     if (uni.enabled) {
         if constexpr (W == 1 && SPL == 5) {
             if (uni.n == 256) return launch_class2<1, 5, false, 256>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
@@ -1459,6 +1468,9 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         }
         if constexpr (W == 4 && SPL == 5) {
             if (uni.n == 1024) return launch_class2<4, 5, false, 1024>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        }
+        if constexpr (W == 4 && SPL == 9) {
+            if (uni.n == 2048) return launch_class2<4, 9, false, 2048>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
         }
         if constexpr (W == 16 && SPL == 5) {
             if (uni.n == 4096) return launch_class2<16, 5, false, 4096>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);

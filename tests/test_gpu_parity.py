@@ -679,9 +679,9 @@ def test_rle_few_runs_fuzz(ctx, A, oracle, seed):
             assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
 
 
-@pytest.mark.parametrize("flen", [128, 256, 512, 1024, 4096])
+@pytest.mark.parametrize("flen", [128, 256, 512, 1024, 2048, 4096])
 def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch, flen):
-    """Uniform batches of 128 / 256 / 512 / 1024 / 4096-sample frames run k_compress<.., FN> (geometry
+    """Uniform batches of 128 / 256 / 512 / 1024 / 2048 / 4096-sample frames run k_compress<.., FN> (geometry
     and FFT stage list folded at compile time); ATSC_NO_UNIFORM forces the table-driven instantiation.
     Same bytes, same errors."""
     import torch
