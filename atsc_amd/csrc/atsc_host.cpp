@@ -304,7 +304,7 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         const int c = class_of(n, p.L);
         const EncLds e = enc_lds(n, p.L, p.direct ? p.bins : p.M, p.direct != 0, p.kcap, c >= 0 && c <= 2);
         p.o_red = e.o_red; p.o_xs = e.o_xs; p.o_tw = e.o_tw; p.o_aux = e.o_aux; p.o_ab = e.o_ab;
-        p.ab_half = e.ab_half; p.ab_bytes = e.ab_bytes; p.o_sel = e.o_sel;
+        p.ab_half = e.ab_half; p.ab_bytes = e.ab_bytes; p.o_sel = e.o_sel; p.o_hist = e.o_hist;
         o = e.total;
     }
     p.lds_bytes = o;

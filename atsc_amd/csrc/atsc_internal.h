@@ -30,7 +30,7 @@ struct DevPlan {
     uint32_t lds_bytes;
     // LDS carve offsets (bytes, 16-aligned).  AB = two FFT work buffers of ab_half bytes each,
     // later reused for spline tables, RLE run records and the RLE hash table.
-    uint32_t o_xs, o_tw, o_ab, ab_half, ab_bytes, o_sel, o_aux, o_red;
+    uint32_t o_xs, o_tw, o_ab, ab_half, ab_bytes, o_sel, o_aux, o_red, o_hist;
     uint64_t tw_off;   // offset (in float2 entries) of this L's table in the twiddle pool
     // The polynomial ladder of a frame of n samples (polynomial.rs:209-277) visits the same
     // (points, step, K) sequence whatever the data: points = base + jump, jump += n/10 (trips 1..17)
@@ -54,8 +54,10 @@ struct DevPlan {
 //   ab   two FFT work buffers of ab_half bytes (8 B per complex point, +8 so the second one can hold
 //        M + 1 bins); later spline tables, RLE run records (>= 8n + 64 bytes) and the RLE hash table
 //   sel  admitted bins, 12 B each
+//   hist multi-wavefront classes only: 256 digit counters + 4 words for the radix select that picks
+//        the kcap bins the ladder can ever admit before they are sorted
 struct EncLds {
-    uint32_t o_red, o_xs, o_tw, o_aux, o_ab, ab_half, ab_bytes, o_sel, total;
+    uint32_t o_red, o_xs, o_tw, o_aux, o_ab, ab_half, ab_bytes, o_sel, o_hist, total;
 };
 #if defined(__HIPCC__)
 #define ATSC_HD __host__ __device__
@@ -77,6 +79,7 @@ ATSC_HD constexpr EncLds enc_lds(uint32_t n, uint32_t L, uint32_t fft_points /* 
     e.o_aux = e.o_tw + 4 * n;
     e.o_ab = o; o += e.ab_bytes;
     e.o_sel = o; o += enc_align16(12 * enc_max(kcap, 1u));
+    e.o_hist = o; o += one_wave ? 0 : 1040;
     e.total = o;
     return e;
 }

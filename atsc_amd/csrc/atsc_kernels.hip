@@ -297,6 +297,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     const uint32_t o_xs = FIX ? lay.o_xs : P.o_xs, o_tw = FIX ? lay.o_tw : P.o_tw, o_ab = FIX ? lay.o_ab : P.o_ab;
     const uint32_t ab_half = FIX ? lay.ab_half : P.ab_half, ab_bytes = FIX ? lay.ab_bytes : P.ab_bytes;
     const uint32_t o_sel = FIX ? lay.o_sel : P.o_sel, o_aux = FIX ? lay.o_aux : P.o_aux, o_red = FIX ? lay.o_red : P.o_red;
+    const uint32_t o_hist = FIX ? lay.o_hist : P.o_hist;
+    const uint32_t kcap = FIX ? ckcap : P.kcap;
 
     double *xs = (double *)(smem + o_xs);
     float2 *tw = (float2 *)(smem + o_tw);
@@ -911,7 +913,64 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 __syncthreads();
             }
             const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
-            if (W > 1) block_sort<W, true>(keys, nullptr, bins, P.p2bins);
+            if (W > 1) {
+                // The ladder can admit kcap bins at most.  The keys are distinct (the position is
+                // part of the key), so the kcap smallest ones are exactly those <= the kcap-th smallest
+                // key: an 8-bit radix select finds it in six counting passes (key bits 16..31 are zero),
+                // the survivors move to the front, and only they are sorted.
+                uint32_t nk = bins;
+                if (bins > kcap && kcap > 0) {
+                    uint32_t *hist = (uint32_t *)(smem + o_hist);  // 256 counters, then {digit, below, count}
+                    uint64_t prefix = 0;
+                    uint32_t remaining = kcap;
+                    for (int shift = 56; shift >= 0; shift -= 8) {
+                        if (shift == 24 || shift == 16) continue;
+                        for (uint32_t i = tid; i < 256; i += T) hist[i] = 0;
+                        __syncthreads();
+                        const uint64_t himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+                        for (uint32_t k = tid; k < bins; k += T) {
+                            const uint64_t v = keys[k];
+                            if ((v & himask) == prefix) atomicAdd(&hist[(uint32_t)(v >> shift) & 255u], 1u);
+                        }
+                        __syncthreads();
+                        if (tid < 64) {  // first digit whose running count reaches `remaining`
+                            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                            const uint32_t sum = c0 + c1 + c2 + c3;
+                            const uint32_t incl = wave_incl_scan_u32(sum);
+                            const uint64_t reach = __ballot(incl >= remaining);
+                            if (reach && tid == (uint32_t)__builtin_ctzll(reach)) {
+                                uint32_t cum = incl - sum, d = 4 * tid;
+                                if (cum + c0 < remaining) { cum += c0; ++d;
+                                    if (cum + c1 < remaining) { cum += c1; ++d;
+                                        if (cum + c2 < remaining) { cum += c2; ++d; } } }
+                                hist[256] = d;
+                                hist[257] = cum;
+                            }
+                        }
+                        __syncthreads();
+                        prefix |= (uint64_t)hist[256] << shift;
+                        remaining -= hist[257];
+                        __syncthreads();
+                    }
+                    constexpr int KPT = SPL / 2 + 1;  // bins <= 32 * W * SPL + 1
+                    uint64_t mine[KPT];
+#pragma unroll
+                    for (int c = 0; c < KPT; ++c) {
+                        const uint32_t k = tid + c * T;
+                        mine[c] = k < bins ? keys[k] : ~0ull;
+                    }
+                    if (tid == 0) hist[258] = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < KPT; ++c)
+                        if (mine[c] <= prefix) keys[atomicAdd(&hist[258], 1u)] = mine[c];
+                    __syncthreads();
+                    nk = kcap;
+                }
+                uint32_t p2 = 1;
+                while (p2 < nk) p2 <<= 1;
+                block_sort<W, true>(keys, nullptr, nk, p2);
+            }
 
             if (prm.debug_stop == 5) return;
             bool fft_pruned = false;

@@ -9,8 +9,8 @@ import numpy as np
 sys.path.insert(0, %r)
 import torch, atsc_amd
 from tests import helpers as H
-n = 40960*256; me = float(np.float32(5)/np.float32(100)); dev = torch.device("cuda:0")
-ctx = atsc_amd.Context(0); off = H.frame_offsets(n, 256); plan = ctx.plan(off); outs = plan.alloc_outputs(torch, dev)
+F = int(os.environ.get("FLEN", "256")); n = 40960*256; me = float(np.float32(5)/np.float32(100)); dev = torch.device("cuda:0")
+ctx = atsc_amd.Context(0); off = H.frame_offsets(n, F); plan = ctx.plan(off); outs = plan.alloc_outputs(torch, dev)
 st = torch.cuda.current_stream().cuda_stream
 res = {}
 for klass in (0, 1, 2, 3, None):
@@ -25,7 +25,7 @@ print(json.dumps(res))
 names = [(1, "load+stats"), (3, "+const/noop/trial checks"), (10, "+RLE bound / early sizing"),
          (11, "+g, 1/|g| registers"), (13, "+poly if first"), (4, "+tw load, fwd FFT"), (5, "+norms, zero cut"),
          (14, "+FFT ladder"), (15, "+poly if second"), (8, "+pending RLE sizing"), (0, "all (+select, emit)")]
-print("%-28s %s" % ("us per 40960 frames", "class 0 / 1 / 2 / 3 / mixed"))
+print("%-28s %s" % ("us per batch of 10.5 M samples, frame length %s" % os.environ.get("FLEN", "256"), "class 0 / 1 / 2 / 3 / mixed"))
 for stop, name in names:
     env = dict(os.environ, ATSC_DEBUG_STOP=str(stop))
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
