@@ -151,10 +151,11 @@ typedef struct {
 int atsc_ctx_enable_diag(atsc_ctx *ctx, int on);
 int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t n_frames);
 
-/* Kernel timing for the roofline report: when on, every atsc_compress_plan_dev records a HIP
- * event pair (on the launch stream) around the k_compress launch of the frame class holding
- * the most frames.  atsc_ctx_profile_read waits for them, returns the summed milliseconds and
- * the number of launches, and resets the counters. */
+/* Kernel timing for the roofline report: when on, every compress call hands a HIP event pair to
+ * the k_compress dispatch of the frame class holding the most frames (hipExtLaunchKernel start /
+ * stop events on the launch stream: the kernel's own timestamps, no marker packets around it; the
+ * large-frame tier, several launches, is bracketed by recorded events).  atsc_ctx_profile_read waits
+ * for them, returns the summed milliseconds and the number of launches, and resets the counters. */
 int atsc_ctx_set_profiling(atsc_ctx *ctx, int on);
 int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *launches);
 
