@@ -34,59 +34,100 @@ DEVI float2 cmulp(float2 v, float2 w)  // v * (w.x + i w.y)
 // workgroup walks a frame, so a stage is bound by memory latency, not bandwidth: the radix switch
 // sits outside the butterfly loop and every thread keeps U butterflies in flight (all their loads are
 // issued before the first result is needed).
-template <int R, int U>
+template <int R>
+DEVI void butterfly_g(const float2 (&a)[R], const float2 (&w)[R], float2 (&y)[R])
+{
+    if (R == 4) {
+        const float2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3 % R];
+        const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+        const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+        const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+        const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+        const float2 t3 = make_float2(d.y, -d.x);
+        y[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+        y[1] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w[1]);
+        y[2 % R] = cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), w[2 % R]);
+        y[3 % R] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w[3 % R]);
+    } else if (R == 2) {
+        const float2 a0 = a[0], a1 = a[1];
+        y[0] = make_float2(a0.x + a1.x, a0.y + a1.y);
+        y[1] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), w[1]);
+    } else {
+        const float2 a0 = a[0], a1 = a[1], a2 = a[2 % R];
+        const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+        const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+        const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+        const float h = 0.8660254037844386f;
+        const float2 t3 = make_float2(h * d.y, -h * d.x);
+        y[0] = make_float2(a0.x + t1.x, a0.y + t1.y);
+        y[1] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), w[1]);
+        y[2 % R] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), w[2 % R]);
+    }
+}
+// One butterfly per thread and iteration, 8-byte accesses (odd strides: transform lengths 3^k).
+template <int R>
 DEVI void fft_stage_g(const float2 *__restrict__ X, float2 *__restrict__ Y, const float2 *__restrict__ tw,
                       uint32_t nb, uint32_t st, uint32_t sm, uint32_t sc, uint32_t magic)
 {
-    for (uint32_t t0 = threadIdx.x; t0 < nb; t0 += LT * U) {
-        float2 a[U][R], w[U][R];
-        uint32_t ob[U];
-        bool live[U];
+    const uint32_t mg = (st == 1) ? 0u : magic;  // __umulhi(t, 0) + t below: no select in the loop
+    for (uint32_t t = threadIdx.x; t < nb; t += LT) {
+        const uint32_t p = (st == 1) ? t : __umulhi(t, mg);
+        const uint32_t q = t - p * st;
+        const uint32_t ib = q + st * p, ob = q + st * (R * p), tb = p * st * sc;
+        float2 a[R], w[R], y[R];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t t = t0 + u * LT;
-            live[u] = t < nb;
-            const uint32_t tt = live[u] ? t : 0;
-            const uint32_t p = (st == 1) ? tt : __umulhi(tt, magic);
-            const uint32_t q = tt - p * st;
-            const uint32_t ib = q + st * p;
-            ob[u] = q + st * (R * p);
-            const uint32_t tb = p * st * sc;
+        for (int j = 0; j < R; ++j) a[j] = X[ib + j * sm];
+        w[0] = make_float2(1.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < R; ++j) a[u][j] = X[ib + j * sm];
+        for (int j = 1; j < R; ++j) w[j] = tw[j * tb];
+        butterfly_g<R>(a, w, y);
 #pragma unroll
-            for (int j = 1; j < R; ++j) w[u][j] = tw[j * tb];
+        for (int k = 0; k < R; ++k) Y[ob + k * st] = y[k];
+    }
+}
+// Two adjacent butterflies per thread and iteration, 16-byte accesses.  Even stride: butterflies
+// (p, q) and (p, q + 1), q even, read and write neighbouring points and share their twiddles.
+// Stride 1 (first stage): butterflies p and p + 1 read neighbouring points and each writes R
+// consecutive ones.  nb and sm are even in both cases.
+template <int R, bool FIRST>
+DEVI void fft_stage_g2(const float2 *__restrict__ X, float2 *__restrict__ Y, const float2 *__restrict__ tw,
+                       uint32_t nb, uint32_t st, uint32_t sm, uint32_t sc, uint32_t magic)
+{
+    // FIRST (st == 1) is a template parameter: as a run-time select inside the loop it turned every
+    // twiddle load into a branch with its own s_waitcnt, i.e. one memory round trip after the other.
+    // (Requesting the next pair's operands before storing the current results was tried as well: no
+    // gain, and the extra live registers spill at 1024 threads per workgroup.  A 70 K-point stage is
+    // about 33 K wavefront-instructions on the CU's four SIMDs: half of the stage time is issue.)
+    for (uint32_t t = 2 * threadIdx.x; t < nb; t += 2 * LT) {
+        const uint32_t p = FIRST ? t : __umulhi(t, magic);
+        const uint32_t q = t - p * st;
+        const uint32_t ib = q + st * p, ob = q + st * (R * p), tb = p * st * sc;
+        float2 a0[R], a1[R], w0[R], w1[R], y0[R], y1[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float4 v = *(const float4 *)(X + ib + j * sm);
+            a0[j] = make_float2(v.x, v.y);
+            a1[j] = make_float2(v.z, v.w);
         }
+        w0[0] = w1[0] = make_float2(1.0f, 0.0f);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!live[u]) continue;
-            const uint32_t o = ob[u];
-            if (R == 4) {
-                const float2 a0 = a[u][0], a1 = a[u][1], a2 = a[u][2], a3 = a[u][3 % R];
-                const float2 t0v = make_float2(a0.x + a2.x, a0.y + a2.y);
-                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
-                const float2 t3 = make_float2(d.y, -d.x);
-                Y[o] = make_float2(t0v.x + t2.x, t0v.y + t2.y);
-                Y[o + st] = cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w[u][1]);
-                Y[o + 2 * st] = cmulc(make_float2(t0v.x - t2.x, t0v.y - t2.y), w[u][2 % R]);
-                Y[o + 3 * st] = cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w[u][3 % R]);
-            } else if (R == 2) {
-                const float2 a0 = a[u][0], a1 = a[u][1];
-                Y[o] = make_float2(a0.x + a1.x, a0.y + a1.y);
-                Y[o + st] = cmulc(make_float2(a0.x - a1.x, a0.y - a1.y), w[u][1]);
-            } else {
-                const float2 a0 = a[u][0], a1 = a[u][1], a2 = a[u][2 % R];
-                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
-                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
-                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
-                const float h = 0.8660254037844386f;
-                const float2 t3 = make_float2(h * d.y, -h * d.x);
-                Y[o] = make_float2(a0.x + t1.x, a0.y + t1.y);
-                Y[o + st] = cmulc(make_float2(t2.x + t3.x, t2.y + t3.y), w[u][1]);
-                Y[o + 2 * st] = cmulc(make_float2(t2.x - t3.x, t2.y - t3.y), w[u][2 % R]);
-            }
+        for (int j = 1; j < R; ++j) {
+            w0[j] = tw[j * tb];
+            w1[j] = FIRST ? tw[j * (tb + sc)] : w0[j];
+        }
+        butterfly_g<R>(a0, w0, y0);
+        butterfly_g<R>(a1, w1, y1);
+        if (FIRST) {
+            float2 yy[2 * R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { yy[k] = y0[k]; yy[R + k] = y1[k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k)  // 2 R consecutive points from ob = R p (even)
+                *(float4 *)(Y + ob + 2 * k) = make_float4(yy[2 * k].x, yy[2 * k].y, yy[2 * k + 1].x, yy[2 * k + 1].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                *(float4 *)(Y + ob + k * st) = make_float4(y0[k].x, y0[k].y, y1[k].x, y1[k].y);
         }
     }
 }
@@ -100,9 +141,25 @@ DEVI float2 *fft_forward_g(const DevPlan &P, float2 *X, float2 *Y, const float2 
         const uint32_t nb = M / r;
         const uint32_t magic = P.stmagic[s];
         const uint32_t sm = st * m;
-        if (r == 4) fft_stage_g<4, 4>(X, Y, tw, nb, st, sm, sc, magic);
-        else if (r == 2) fft_stage_g<2, 4>(X, Y, tw, nb, st, sm, sc, magic);
-        else fft_stage_g<3, 4>(X, Y, tw, nb, st, sm, sc, magic);
+        // pairs need neighbouring butterflies to be neighbours in memory and every 16-byte access
+        // aligned: an even stride (then nb and sm are even too), or the first stage with an even
+        // number of butterflies; transform lengths 3^k run the single-butterfly form
+        const bool pairs = (st % 2 == 0) || (st == 1 && nb % 2 == 0 && sm % 2 == 0);
+        if (pairs) {
+            if (st == 1) {
+                if (r == 4) fft_stage_g2<4, true>(X, Y, tw, nb, st, sm, sc, magic);
+                else if (r == 2) fft_stage_g2<2, true>(X, Y, tw, nb, st, sm, sc, magic);
+                else fft_stage_g2<3, true>(X, Y, tw, nb, st, sm, sc, magic);
+            } else {
+                if (r == 4) fft_stage_g2<4, false>(X, Y, tw, nb, st, sm, sc, magic);
+                else if (r == 2) fft_stage_g2<2, false>(X, Y, tw, nb, st, sm, sc, magic);
+                else fft_stage_g2<3, false>(X, Y, tw, nb, st, sm, sc, magic);
+            }
+        } else {
+            if (r == 4) fft_stage_g<4>(X, Y, tw, nb, st, sm, sc, magic);
+            else if (r == 2) fft_stage_g<2>(X, Y, tw, nb, st, sm, sc, magic);
+            else fft_stage_g<3>(X, Y, tw, nb, st, sm, sc, magic);
+        }
         __syncthreads();
         float2 *tmp = X; X = Y; Y = tmp;
         ncur = m;
