@@ -25,19 +25,20 @@ hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const do
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
-                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s);
+                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
+                                 const LargePre *pre = nullptr);
 uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, hipStream_t s);
+                                   uint32_t ws_slots, int tiled, hipStream_t s);
 hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
                                 uint32_t *hist_cursor, const uint32_t *class_first,
                                 const uint32_t *class_count, int n_classes, hipStream_t s);
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
-                       hipStream_t s);
+                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s);
 hipError_t launch_decompress(const struct DevDFrame *frames, uint64_t n_frames, const uint32_t *ids,
                              int cls, uint32_t count, uint32_t lds, const DevPlan *plans,
                              const float2 *twpool, const uint8_t *body, double *out, int *status,
@@ -83,6 +84,7 @@ struct PlanTables {
 //    frame that is at least that long (frame/mod.rs:89-111)
 //  * FFT::compress (unbounded): no Gibbs padding, transform length = frame length (fft.rs:366-388)
 struct SubPlan {
+    bool large_tiled = false;
     PlanTables tabs;
     DevFrame *d_frames = nullptr;
     uint32_t *d_ids = nullptr;
@@ -109,6 +111,8 @@ struct atsc_plan {
     unsigned char *d_ws = nullptr;   // workspace of the large-frame kernel
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
+    bool large_tiled = false;        // form of the large tier's in-kernel transforms
+    LargePre large_pre{0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
     // atsc_compress_plan_dev_pipelined: a second scratch set (allocated on first use) so that the
     // packing of batch i (context's pack stream) overlaps the codecs of batch i+1 (caller's stream)
     struct Scratch {
@@ -142,6 +146,7 @@ struct atsc_dplan {
     unsigned char *d_ws = nullptr;
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
+    bool large_tiled = false;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -194,16 +199,32 @@ extern "C" uint64_t atsc_payload_bound_bytes(uint64_t n)
     return 32 + (n > 65535 ? 17 : 14) * n;
 }
 
-// Large-frame transform of a plan: two LDS-tiled passes when the batch has more large frames than
-// the GPU has CUs to give them (fewer bytes through L2: 15.7 vs 14.3 Gsamples/s at 256+ frames), the
-// stage-by-stage form when every frame has a CU to itself and latency is what counts (6.8 vs 6.0
-// Gsamples/s at 80 frames).  ATSC_LARGE_FFT=tiled|stages overrides (tests, experiments).
-static void choose_large_fft(std::vector<DevPlan> &plans, uint32_t n_large_frames)
+// Form of the transforms that run inside the large-frame kernels: two LDS-tiled passes when the
+// batch has more large frames than the GPU has CUs to give them (fewer bytes through L2: 15.7 vs
+// 14.3 Gsamples/s at 256+ frames), stage by stage when every frame has a CU to itself and latency is
+// what counts (6.8 vs 6.0 Gsamples/s at 80 frames).  ATSC_LARGE_FFT=tiled|stages overrides.
+static bool choose_large_tiled(uint32_t n_large_frames)
 {
     bool tiled = n_large_frames > 128;
     if (const char *e = getenv("ATSC_LARGE_FFT")) tiled = strcmp(e, "tiled") == 0;
-    if (!tiled)
-        for (DevPlan &p : plans) p.f4_m1 = p.f4_m2 = 0;
+    return tiled;
+}
+// Grid extents of the batched pre-pass (forward transform, untangle, norms of every large frame over
+// the whole GPU before the per-frame kernel); all zero when a large frame length has no M1 x M2 split.
+static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
+{
+    LargePre pre{0, 0, 0, 0, 0};
+    if (getenv("ATSC_LARGE_NO_PREPASS")) return pre;
+    for (uint32_t pi : large_plan_ids) {
+        const DevPlan &p = plans[pi];
+        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0};
+        pre.tiles1 = std::max(pre.tiles1, (p.f4_m2 + 15) / 16);
+        pre.tiles2 = std::max(pre.tiles2, (p.f4_m1 + 15) / 16);
+        pre.chunks = std::max(pre.chunks, (p.bins + 255) / 256);
+        pre.m1_max = std::max(pre.m1_max, p.f4_m1);
+        pre.m2_max = std::max(pre.m2_max, p.f4_m2);
+    }
+    return pre;
 }
 
 static int class_of(uint32_t n, uint32_t L)
@@ -571,7 +592,15 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
             u.plan = f0.plan;
         }
     }
-    choose_large_fft(p->tabs.plans, p->class_count[CLASS_LARGE]);
+    p->large_tiled = choose_large_tiled(p->class_count[CLASS_LARGE]);
+    if (p->class_count[CLASS_LARGE]) {
+        std::vector<uint32_t> lp;
+        for (uint64_t f = 0; f < n_frames; ++f)
+            if (cls[f] == CLASS_LARGE) lp.push_back(frames[f].plan);
+        std::sort(lp.begin(), lp.end());
+        lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
+        p->large_pre = large_pre_extents(p->tabs.plans, lp);
+    }
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_plan_destroy(p); return rc; }
     const uint32_t nb = (uint32_t)((n_frames + 1023) / 1024);
@@ -647,7 +676,7 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
         for (int c = 0; c < N_CLASSES; ++c) { t->class_first[c] = acc; acc += t->class_count[c]; }
         std::vector<uint32_t> cur(t->class_first);
         for (size_t i = 0; i < sel.size(); ++i) ids[cur[cls[i]]++] = sel[i];
-        choose_large_fft(t->tabs.plans, t->class_count[CLASS_LARGE]);
+        t->large_tiled = choose_large_tiled(t->class_count[CLASS_LARGE]);
         int rc = upload_tables(ctx, t->tabs);
         if (rc) { free_sub(t); return rc; }
 #define TCHK(call)                                                                      \
@@ -675,10 +704,14 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
     for (int c = 0; c < N_CLASSES; ++c) {
         if (!t->class_count[c]) continue;
         hipError_t e;
-        if (c == CLASS_LARGE)
+        if (c == CLASS_LARGE) {
+            KParams lp = prm;
+            lp.large_tiled = t->large_tiled ? 1u : 0u;
+            lp.prefft = 0;
             e = launch_compress_large(t->class_count[c], d_samples, t->d_frames, t->d_ids + t->class_first[c],
-                                      t->tabs.d_plans, t->tabs.d_tw, prm, d_slots, res, diag,
+                                      t->tabs.d_plans, t->tabs.d_tw, lp, d_slots, res, diag,
                                       plan->d_ws, plan->ws_stride, plan->ws_slots, s);
+        }
         else
             e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
                                       t->d_ids + t->class_first[c], t->tabs.d_plans, t->tabs.d_tw,
@@ -768,7 +801,8 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             HIPCHK(ctx, hipStreamWaitEvent(ps, codec_done, 0));
         }
         hipError_t e = launch_pack(plan->d_frames, S.d_res, plan->n_frames, S.d_local, S.d_blocksum,
-                                   S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err, ps);
+                                   S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err,
+                                   plan->d_ids + plan->class_first[CLASS_LARGE], plan->class_count[CLASS_LARGE], ps);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
         if (pipelined) {
             if (adapt && want_order) {
@@ -823,6 +857,8 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.trial_min_n = 0;
     prm.trial_res = nullptr;
     prm.cost = nullptr;
+    prm.large_tiled = 0;
+    prm.prefft = 0;
     if (compressor == ATSC_AUTO && sample_level > 0) {
         if (!plan->trials[sample_level]) {
             SubPlan *t = nullptr;
@@ -884,11 +920,17 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             codec_done = ev1;
         }
         hipError_t e;
-        if (c == CLASS_LARGE)
+        if (c == CLASS_LARGE) {
+            KParams lp = prm;
+            lp.large_tiled = plan->large_tiled ? 1u : 0u;
+            // the pre-pass transforms every large frame; a trial launch or a forced codec other than
+            // FFT / Auto would not use its results
+            const bool pre = plan->large_pre.tiles1 && (compressor == ATSC_AUTO || compressor == ATSC_FFT);
             e = launch_compress_large(plan->class_count[c], d_samples, plan->d_frames,
                                       plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
-                                      plan->tabs.d_tw, prm, S.d_slots, S.d_res, d_diag, plan->d_ws,
-                                      plan->ws_stride, plan->ws_slots, s);
+                                      plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag, plan->d_ws,
+                                      plan->ws_stride, plan->ws_slots, s, pre ? &plan->large_pre : nullptr);
+        }
         else {
             UniArgs u = plan->class_uni[c];
             u.adaptive = (ids_main != plan->d_ids) ? 1u : 0u;
@@ -1160,7 +1202,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         std::vector<uint32_t> cur(p->class_first);
         for (size_t f = 0; f < frames.size(); ++f) ids[cur[cls[f]]++] = (uint32_t)f;
     }
-    choose_large_fft(p->tabs.plans, p->class_count[CLASS_LARGE]);
+    p->large_tiled = choose_large_tiled(p->class_count[CLASS_LARGE]);
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_dplan_destroy(p); return rc; }
 #define PCHK(call)                                                                      \
@@ -1194,7 +1236,7 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
         if (c == CLASS_LARGE)
             e = launch_decompress_large(dp->class_count[c], dp->d_frames, dp->d_ids + dp->class_first[c],
                                         dp->tabs.d_plans, dp->tabs.d_tw, d_body, d_out, dp->d_status,
-                                        dp->d_ws, dp->ws_stride, dp->ws_slots, s);
+                                        dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0, s);
         else
             e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
                                   dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,

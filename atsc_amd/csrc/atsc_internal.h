@@ -25,8 +25,8 @@ struct DevPlan {
     uint32_t p2bins;   // power of two >= bins (sort network size)
     uint32_t p2n;      // power of two >= n
     uint32_t magicL;   // floor(2^32 / L) + 1 (L >= 2): x mod L without a divide
-    uint32_t f4_m1, f4_m2;  // M = f4_m1 * f4_m2, f4_m1 <= f4_m2 as close as the factors allow: the
-                            // large tier transforms in two LDS-tiled passes (0: keep the stage-by-stage form)
+    uint32_t f4_m1, f4_m2;  // M = f4_m1 * f4_m2, f4_m1 <= f4_m2 as close as the factors allow (0: no usable
+                            // split): the large tier's LDS-tiled two-pass transform
     uint32_t lds_bytes;
     // LDS carve offsets (bytes, 16-aligned).  AB = two FFT work buffers of ab_half bytes each,
     // later reused for spline tables, RLE run records and the RLE hash table.
@@ -113,6 +113,15 @@ struct KParams {
     uint32_t trial_min_n;        // COMPRESSION_SPEED[level]; frames at least this long use the trial's codec
     const DevResult *trial_res;  // results of the trial launch (indexed like the frames), or null
     uint32_t *cost;              // per frame: shader clocks / 64 this launch took (scheduling hint), or null
+    uint32_t large_tiled;        // large tier: in-kernel transforms take the LDS-tiled two-pass form
+    uint32_t prefft;             // large tier: forward transform, untangle and norms were done by the
+                                 // batched pre-pass kernels (spectrum, norm bits and non-zero count are
+                                 // in the frame's workspace slot)
+};
+// grid extents of the large tier's pre-pass over a plan's large frames (0 tiles: no pre-pass)
+struct LargePre {
+    uint32_t tiles1, tiles2, chunks;  // max over frame lengths: column tiles, row tiles, 256-bin chunks
+    uint32_t m1_max, m2_max;          // longest sub-transforms: size the tile buffers in LDS
 };
 
 // Uniform launch: every frame of the class has the same length and frame f of the class sits at

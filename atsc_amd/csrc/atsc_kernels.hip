@@ -1432,7 +1432,8 @@ __global__ __launch_bounds__(256) void k_pack_scan2(uint64_t *__restrict__ block
 // workgroup never straddles a chunk: PACK_CHUNK is a multiple of 32).
 constexpr int EMIT_LANES = 8;
 constexpr int EMIT_FRAMES = 256 / EMIT_LANES;  // frames per workgroup
-template <bool FUSED>
+constexpr uint32_t EMIT_BIG_N = 4096;  // frames of the large tier: payloads of kilobytes
+template <bool FUSED, bool BIGSEP>
 __global__ __launch_bounds__(256) void k_pack_emit(
     const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
     const uint32_t *__restrict__ local, const uint64_t *__restrict__ blocksum,
@@ -1471,6 +1472,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
         p += put_varint(p, r.chosen);
         p += put_varint(p, r.len);
     }
+    if (BIGSEP && fr.n > EMIT_BIG_N) return;  // k_pack_emit_big copies this payload with a workgroup
     const uint8_t *src = slots + fr.slot_off;
     uint8_t *pd = dst + hl;
     const uint32_t whole = r.len & ~7u;
@@ -1479,6 +1481,31 @@ __global__ __launch_bounds__(256) void k_pack_emit(
         __builtin_memcpy(pd + b, &v, 8);
     }
     if (whole + l8 < r.len) pd[whole + l8] = src[whole + l8];  // at most 7 trailing bytes
+}
+
+// Payloads of large frames: one workgroup per frame, 16 bytes per lane (source 16-byte aligned).
+// The record header was written by k_pack_emit; rec_off[f] is the record's offset.
+__global__ __launch_bounds__(256) void k_pack_emit_big(const DevFrame *__restrict__ frames,
+                                                       const DevResult *__restrict__ res,
+                                                       const uint32_t *__restrict__ big_ids,
+                                                       const uint64_t *__restrict__ rec_off,
+                                                       const uint8_t *__restrict__ slots,
+                                                       uint8_t *__restrict__ body, uint64_t body_cap)
+{
+    const uint32_t f = big_ids[blockIdx.x];
+    const DevFrame fr = frames[f];
+    const DevResult r = res[f];
+    const uint64_t off = rec_off[f];
+    const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
+    if (off + hl + r.len > body_cap) return;
+    const uint8_t *src = slots + fr.slot_off;
+    uint8_t *pd = body + off + hl;
+    const uint32_t whole = r.len & ~15u;
+    for (uint32_t b = threadIdx.x * 16; b < whole; b += 256 * 16) {
+        const uint4 v = *(const uint4 *)(src + b);
+        __builtin_memcpy(pd + b, &v, 16);
+    }
+    if (whole + threadIdx.x < r.len) pd[whole + threadIdx.x] = src[whole + threadIdx.x];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1558,20 +1585,32 @@ hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const do
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
-                       hipStream_t s)
+                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s)
 {
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
     const dim3 eg((uint32_t)((n_frames + EMIT_FRAMES - 1) / EMIT_FRAMES));
+    const bool big = n_big != 0;
     if (nb <= 64) {
-        hipLaunchKernelGGL(k_pack_emit<true>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                           slots, body, body_cap, rec_off, chosen, err);
+        if (big)
+            hipLaunchKernelGGL((k_pack_emit<true, true>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                               slots, body, body_cap, rec_off, chosen, err);
+        else
+            hipLaunchKernelGGL((k_pack_emit<true, false>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                               slots, body, body_cap, rec_off, chosen, err);
     } else {
         hipLaunchKernelGGL(k_pack_scan2, dim3(1), dim3(256), 0, s, blocksum, nb);
-        hipLaunchKernelGGL(k_pack_emit<false>, eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                           slots, body, body_cap, rec_off, chosen, err);
+        if (big)
+            hipLaunchKernelGGL((k_pack_emit<false, true>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                               slots, body, body_cap, rec_off, chosen, err);
+        else
+            hipLaunchKernelGGL((k_pack_emit<false, false>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
+                               slots, body, body_cap, rec_off, chosen, err);
     }
+    if (big)
+        hipLaunchKernelGGL(k_pack_emit_big, dim3(n_big), dim3(256), 0, s, frames, res, big_ids, rec_off, slots,
+                           body, body_cap);
     return hipGetLastError();
 }
 

@@ -185,7 +185,8 @@ constexpr uint32_t F4_TILE = FB * (F4_MAX + 1);  // float2 per tile buffer
 // Stockham over `nseq` sequences of length N held in LDS, element (i, c) at i * si + c * sq.
 // CF: consecutive work items walk the sequences first (si = FB, sq = 1), else the butterflies first.
 template <bool CF>
-DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_t nseq, uint32_t si, uint32_t sq)
+DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_t nseq, uint32_t si, uint32_t sq,
+                     uint32_t nt = LT)
 {
     uint32_t ncur = N, st = 1;
     while (ncur > 1) {
@@ -194,7 +195,7 @@ DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_
         const uint32_t mg_st = st > 1 ? (uint32_t)(0x100000000ull / st) + 1u : 0u;
         const uint32_t mg_nb = nbf > 1 ? (uint32_t)(0x100000000ull / nbf) + 1u : 0u;
         const uint32_t total = CF ? nbf * FB : nbf * nseq;
-        for (uint32_t w = threadIdx.x; w < total; w += LT) {
+        for (uint32_t w = threadIdx.x; w < total; w += nt) {
             uint32_t b, c;
             if (CF) { c = w & (FB - 1); b = w >> 4; if (c >= nseq) continue; }
             else { c = nbf > 1 ? __umulhi(w, mg_nb) : w; b = w - c * nbf; }
@@ -283,16 +284,16 @@ DEVI float2 *fft_tiled_g(const DevPlan &P, float2 *X, float2 *Y, const float2 *t
     return X;
 }
 // the transform the large tier uses: tiled when the plan has a split, stage by stage otherwise
-DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw, float2 *lds)
+DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw, float2 *lds, bool tiled)
 {
-    if (P.f4_m1) return fft_tiled_g(P, X, Y, tw, lds);
+    if (tiled && P.f4_m1) return fft_tiled_g(P, X, Y, tw, lds);
     return fft_forward_g(P, X, Y, tw);
 }
 
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -313,6 +314,7 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_rps = o; o += lw_align(4ull * (n + 8));
     w.o_rph = o; o += lw_align(4ull * (n + 8));
     w.o_spos = o; o += lw_align(4ull * (16384 + 8));  // admission order (bin positions) once sorted: frees the LDS
+    w.o_cnt = o; o += lw_align(16);                   // pre-pass: number of ZERO bins (rare: few atomics)
     w.bytes = o;
     return w;
 }
@@ -352,6 +354,154 @@ DEVI void sort_runs_g(uint64_t *rec, const double *xs, uint32_t count, uint32_t 
             }
             __syncthreads();
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Pre-pass of the large tier.  A frame's forward transform does not depend on anything the frame
+// decides later, and one workgroup per frame leaves most of the GPU idle when a batch has fewer large
+// frames than CUs (80 frames for BASELINE's 10 M samples in the reference chunker's framing).  So the
+// forward transform, the untangle step and the norms of ALL large frames of a launch run first, as
+// three kernels over (tile, frame) grids that use every CU; k_compress_large (prm.prefft) then starts
+// from the spectrum in its workspace slot.  Same two-pass M1 x M2 scheme as fft_tiled_g.
+// --------------------------------------------------------------------------------------------
+constexpr int PT = 1024;  // threads of a pre-pass workgroup (a tile stage is ~1300 butterflies)
+
+struct PreFrame {
+    const double *xs;
+    unsigned char *ws;
+    uint32_t n, L, M, pre, half, M1, M2, sc, bins;
+};
+DEVI PreFrame pre_frame(const double *samples, const DevFrame *frames, const uint32_t *ids,
+                        const DevPlan *plans, unsigned char *ws_base, uint64_t ws_stride, const DevPlan *&P)
+{
+    const DevFrame fr = frames[ids[blockIdx.y]];
+    P = &plans[fr.plan];
+    PreFrame f;
+    f.xs = samples + fr.sample_off;
+    f.ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    f.n = fr.n; f.L = P->L; f.M = P->M; f.pre = P->pre; f.half = P->half;
+    f.M1 = P->f4_m1; f.M2 = P->f4_m2; f.sc = P->sc; f.bins = P->bins;
+    return f;
+}
+// pass 1: FB columns of the packed (even L) or complex (odd L) padded f32 signal
+__global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ samples,
+                                                    const DevFrame *__restrict__ frames,
+                                                    const uint32_t *__restrict__ ids,
+                                                    const DevPlan *__restrict__ plans,
+                                                    const float2 *__restrict__ twpool,
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevPlan *P;
+    const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
+    const uint32_t c0 = blockIdx.x * FB;
+    if (c0 >= f.M2) return;
+    const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
+    float2 *Y = (float2 *)(f.ws + lay.o_b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t *)(f.ws + lay.o_cnt) = 0;
+    const float2 *tw = twpool + P->tw_off;
+    float2 *T = (float2 *)smem, *U = T + FB * f.M1, *w1 = U + FB * f.M1;
+    for (uint32_t e = threadIdx.x; e < f.M1; e += PT) w1[e] = tw[e * (f.M2 * f.sc)];
+    const uint32_t nseq = min(FB, f.M2 - c0);
+    auto g = [&](uint32_t j) -> float {  // fft.rs:184-204, then `as f32`
+        int32_t i = (int32_t)j - (int32_t)f.pre;
+        i = i < 0 ? 0 : (i >= (int32_t)f.n ? (int32_t)f.n - 1 : i);
+        return (float)f.xs[i];
+    };
+    for (uint32_t w = threadIdx.x; w < f.M1 * FB; w += PT) {
+        const uint32_t c = w & (FB - 1), n1 = w >> 4;
+        if (c < nseq) {
+            const uint32_t i = f.M2 * n1 + c0 + c;
+            T[n1 * FB + c] = f.half ? make_float2(g(2 * i), g(2 * i + 1)) : make_float2(g(i), 0.0f);
+        }
+    }
+    __syncthreads();
+    const float2 *R = lds_fft<true>(T, U, w1, f.M1, nseq, FB, 1, PT);
+    for (uint32_t w = threadIdx.x; w < f.M1 * FB; w += PT) {
+        const uint32_t c = w & (FB - 1), k1 = w >> 4;
+        if (c < nseq) {
+            const uint32_t n2 = c0 + c;
+            Y[k1 * f.M2 + n2] = cmulc(R[k1 * FB + c], tw[n2 * k1 * f.sc]);
+        }
+    }
+}
+// pass 2: FB rows
+__global__ __launch_bounds__(PT) void k_large_pre2(const double *__restrict__ samples,
+                                                    const DevFrame *__restrict__ frames,
+                                                    const uint32_t *__restrict__ ids,
+                                                    const DevPlan *__restrict__ plans,
+                                                    const float2 *__restrict__ twpool,
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevPlan *P;
+    const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
+    const uint32_t r0 = blockIdx.x * FB;
+    if (r0 >= f.M1) return;
+    const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
+    const float2 *Y = (const float2 *)(f.ws + lay.o_b);
+    float2 *X = (float2 *)(f.ws + lay.o_a);
+    const float2 *tw = twpool + P->tw_off;
+    const uint32_t ld = f.M2 + 1;
+    float2 *T = (float2 *)smem, *U = T + FB * ld, *w2 = U + FB * ld;
+    for (uint32_t e = threadIdx.x; e < f.M2; e += PT) w2[e] = tw[e * (f.M1 * f.sc)];
+    const uint32_t nseq = min(FB, f.M1 - r0);
+    const uint32_t mg_m2 = (uint32_t)(0x100000000ull / f.M2) + 1u;
+    for (uint32_t w = threadIdx.x; w < nseq * f.M2; w += PT) {
+        const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * f.M2;
+        T[r * ld + n2] = Y[(r0 + r) * f.M2 + n2];
+    }
+    __syncthreads();
+    const float2 *R = lds_fft<false>(T, U, w2, f.M2, nseq, 1, ld, PT);
+    for (uint32_t w = threadIdx.x; w < f.M2 * FB; w += PT) {
+        const uint32_t r = w & (FB - 1), k2 = w >> 4;
+        if (r < nseq) X[(r0 + r) + f.M1 * k2] = R[r * ld + k2];
+    }
+}
+// untangle (even L) + norm bits + non-zero count + empty admitted spectrum, 256 bins per workgroup
+constexpr int PT3 = 256;
+__global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ samples,
+                                                    const DevFrame *__restrict__ frames,
+                                                    const uint32_t *__restrict__ ids,
+                                                    const DevPlan *__restrict__ plans,
+                                                    const float2 *__restrict__ twpool,
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    const DevPlan *P;
+    const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
+    const uint32_t k = blockIdx.x * PT3 + threadIdx.x;
+    if (blockIdx.x * PT3 >= f.bins) return;
+    const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
+    const float2 *Z = (const float2 *)(f.ws + lay.o_a);
+    float2 *spec = f.half ? (float2 *)(f.ws + lay.o_b) : (float2 *)(f.ws + lay.o_a);
+    uint32_t *nbits = (uint32_t *)(f.ws + lay.o_nb);
+    float2 *Xs = (float2 *)(f.ws + lay.o_x);
+    const float2 *tw = twpool + P->tw_off;
+    uint32_t zeros = 0;
+    if (k < f.bins) {
+        float2 z;
+        if (f.half) {  // see fft_untangle (atsc_kernels.hip); bins = M + 1
+            const uint32_t M = f.M;
+            const float2 zk = Z[k == M ? 0 : k];
+            const float2 zm = Z[k == 0 ? 0 : M - k];
+            const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 t = cmulc(make_float2(b.y, -b.x), tw[k]);
+            z = make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+            spec[k] = z;
+        } else {
+            z = Z[k];
+        }
+        nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+        zeros = (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
+        Xs[k] = make_float2(0.0f, 0.0f);
+    }
+    // fft.rs:249-252 needs the number of non-zero bins; zero bins are the rare ones, so they are what
+    // gets counted (a same-address atomic per wavefront serialised ~1100 deep per frame otherwise)
+    if (__ballot(zeros != 0)) {
+        zeros = wave_sum_u32(zeros);
+        if ((threadIdx.x & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
     }
 }
 
@@ -584,11 +734,13 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             bool fft_pruned = false;
             // ---- forward transform of the padded f32 signal ----
             float2 *spec;
-            if (P.half) {
+            if (prm.prefft) {
+                spec = P.half ? B : A;  // k_large_pre1..3 left the spectrum, nbits, Xs = 0 and the count
+            } else if (P.half) {
                 float *Af = (float *)A;
                 for (uint32_t j = tid; j < L; j += T) Af[j] = (float)gpad(j);
                 __syncthreads();
-                float2 *Z = fft_large(P, A, B, tw, fft_lds);
+                float2 *Z = fft_large(P, A, B, tw, fft_lds, prm.large_tiled != 0);
                 spec = (Z == A) ? B : A;
                 for (uint32_t k = tid; k <= M; k += T) {  // untangle (see fft_untangle)
                     const float2 zk = Z[k == M ? 0 : k];
@@ -602,21 +754,26 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             } else {
                 for (uint32_t j = tid; j < L; j += T) A[j] = make_float2((float)gpad(j), 0.0f);
                 __syncthreads();
-                spec = fft_large(P, A, B, tw, fft_lds);
+                spec = fft_large(P, A, B, tw, fft_lds, prm.large_tiled != 0);
             }
             float2 *work = (spec == A) ? B : A;  // free FFT buffer from here on
             if (prm.debug_stop == 4) return;
 
             // ---- admission order: the kcap largest norms, descending, ties by position ----
-            uint32_t nz = 0;
-            for (uint32_t k = tid; k < bins; k += T) {
-                const float2 z = spec[k];
-                nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
-                nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                Xs[k] = make_float2(0.0f, 0.0f);
+            uint32_t Z;
+            if (prm.prefft) {
+                Z = bins - *(const uint32_t *)(ws + lay.o_cnt);
+            } else {
+                uint32_t nz = 0;
+                for (uint32_t k = tid; k < bins; k += T) {
+                    const float2 z = spec[k];
+                    nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+                    nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
+                    Xs[k] = make_float2(0.0f, 0.0f);
+                }
+                __syncthreads();
+                Z = block_sum_u32<W>(nz, red, parity);
             }
-            __syncthreads();
-            const uint32_t Z = block_sum_u32<W>(nz, red, parity);
             const uint32_t kcap = min(P.kcap, LKEYS_MAX);
             uint32_t nkeys = 0;
             if (bins <= kcap) {
@@ -755,7 +912,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         work[k] = make_float2(e.x - o.y, -(e.y + o.x));
                     }
                     __syncthreads();
-                    F = fft_large(P, work, Cb, tw, fft_lds);
+                    F = fft_large(P, work, Cb, tw, fft_lds, prm.large_tiled != 0);
                 } else {
                     for (uint32_t k = tid; k < L; k += T) {
                         float2 v = make_float2(0.0f, 0.0f);
@@ -764,7 +921,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         work[k] = make_float2(v.x, -v.y);  // conj for inverse-by-forward
                     }
                     __syncthreads();
-                    F = fft_large(P, work, Cb, tw, fft_lds);
+                    F = fft_large(P, work, Cb, tw, fft_lds, prm.large_tiled != 0);
                 }
                 // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
                 double s = 0.0;
@@ -1115,16 +1272,37 @@ __global__ __launch_bounds__(LT) void k_compress_large(
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
-                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s)
+                                 unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
+                                 const LargePre *pre)
 {
     const uint32_t lds = 384 + 1024 + 64 + 8 * LKEYS_MAX;
     hipError_t e = hipFuncSetAttribute((const void *)k_compress_large,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    KParams kp = prm;
+    kp.prefft = (pre && pre->tiles1) ? 1u : 0u;
+    // tile buffers of a pre-pass workgroup: two of FB x (sub-transform length [+ 1]) points + its twiddles
+    uint32_t lds1 = 0, lds2 = 0;
+    if (kp.prefft) {
+        lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
+        lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
+        e = hipFuncSetAttribute((const void *)k_large_pre1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_large_pre2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+    }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
+        if (kp.prefft) {
+            hipLaunchKernelGGL(k_large_pre1, dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames, ids + b0,
+                               plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_pre2, dim3(pre->tiles2, nb), dim3(PT), lds2, s, samples, frames, ids + b0,
+                               plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_pre3, dim3(pre->chunks, nb), dim3(PT3), 0, s, samples, frames, ids + b0,
+                               plans, twpool, ws, ws_stride);
+        }
         hipLaunchKernelGGL(k_compress_large, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
-                           twpool, prm, slots, res, diag, ws, ws_stride);
+                           twpool, kp, slots, res, diag, ws, ws_stride);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1139,7 +1317,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
     const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
-    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled)
 {
     constexpr int T = LT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1359,7 +1537,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             }
         }
         __syncthreads();
-        F = fft_large(P, A, Cb, tw, (float2 *)(smem + 256));
+        F = fft_large(P, A, Cb, tw, (float2 *)(smem + 256), tiled != 0);
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
         for (uint32_t i = tid; i < n; i += T) {
@@ -1399,7 +1577,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
 hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, hipStream_t s)
+                                   uint32_t ws_slots, int tiled, hipStream_t s)
 {
     // 256 B of header scratch + the tile buffers of the LDS-tiled inverse transform
     const uint32_t lds = 256 + (2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2);
@@ -1409,7 +1587,7 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
         hipLaunchKernelGGL(k_decompress_large, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                           body, out, status, ws, ws_stride);
+                           body, out, status, ws, ws_stride, tiled);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
