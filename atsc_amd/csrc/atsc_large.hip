@@ -675,7 +675,25 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         __syncthreads();
         uint32_t p2 = 1;
         while (p2 < R) p2 <<= 1;
-        sort_runs_g(rrec, xs, R, p2);
+        if (R <= 8192) {
+            // up to 8192 runs: sort (value bits, run index) in LDS -- the run index is the start order --
+            // instead of a network over global memory that looks every key up through xs[]
+            uint64_t *kk = keys;                      // 8 R bytes
+            uint32_t *pp = (uint32_t *)(keys + R);    // 4 R bytes; 12 R <= 96 KB of the 128 KB key buffer
+            for (uint32_t r = tid; r < R; r += T) {
+                kk[r] = run_key(rrec[r]);
+                pp[r] = r;
+            }
+            __syncthreads();
+            block_sort<W, false>(kk, pp, R, p2);
+            uint64_t *tmp = (uint64_t *)tab;          // 8 (n + 8) bytes of scratch, free here
+            for (uint32_t i = tid; i < R; i += T) tmp[i] = rrec[pp[i]];
+            __syncthreads();
+            for (uint32_t i = tid; i < R; i += T) rrec[i] = tmp[i];
+            __syncthreads();
+        } else {
+            sort_runs_g(rrec, xs, R, p2);
+        }
         for (uint32_t i = tid; i < R; i += T)
             aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
         __syncthreads();
