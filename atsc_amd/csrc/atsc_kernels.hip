@@ -660,6 +660,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 double2 *mm = (double2 *)AB;  // per-segment Hermite tangents (m0, m1); AB is free here
                 const double inv_n = P.inv_n;
                 const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
+                const bool nozero = smin > 0.0 || smax < 0.0;                  // every 1/|g| is finite
                 double cur = prm.max_err + 1.0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
                     const uint32_t ti = poly_trips;  // 0 .. 22
@@ -747,55 +748,69 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                             }
                         }
                         __syncthreads();
-                        double s = 0.0;
-#pragma unroll
-                        for (int m = 0; m < SPL; ++m) {
+                        // one sample's share of the MAPE sum (slice m of the padded layout)
+                        auto term = [&](const int m) -> double {
                             const uint32_t j = tid + m * T;
-                            if (j >= pre && j < pre + n) {
-                                const uint32_t i = j - pre;
-                                double sv;
-                                if (i == n - 1) {
-                                    sv = xs[n - 1];
-                                } else {
-                                    uint32_t sg = __umulhi(i, magic);  // i / step
-                                    if (sg > K - 2) sg = K - 2;
-                                    const uint32_t t0i = sg * step;
-                                    const bool last = (sg == K - 2);
-                                    const uint32_t t1i = last ? (n - 1) : t0i + step;
-                                    const double v0 = xs[t0i], v1 = xs[t1i];
-                                    if (sg > 0 && !last) {  // Catmull-Rom: sg in 1..K-3
-                                        const double2 t = mm[sg];
-                                        if (use_tab) {
-                                            const double4 h = hb[i - t0i];
-                                            sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
-                                        } else {
-                                            const double nt = div_small((double)(i - t0i), stepd, ry);
-                                            const double t2 = nt * nt;
-                                            const double t3 = t2 * nt;
-                                            const double two_t3 = t3 * 2.0;
-                                            const double two_t2 = t2 * 2.0;
-                                            const double three_t2 = t2 * 3.0;
-                                            sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
-                                                 v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
-                                        }
+                            if (!(j >= pre && j < pre + n)) return 0.0;
+                            const uint32_t i = j - pre;
+                            double sv;
+                            if (i == n - 1) {
+                                sv = xs[n - 1];
+                            } else {
+                                uint32_t sg = __umulhi(i, magic);  // i / step
+                                if (sg > K - 2) sg = K - 2;
+                                const uint32_t t0i = sg * step;
+                                const bool last = (sg == K - 2);
+                                const uint32_t t1i = last ? (n - 1) : t0i + step;
+                                const double v0 = xs[t0i], v1 = xs[t1i];
+                                if (sg > 0 && !last) {  // Catmull-Rom: sg in 1..K-3
+                                    const double2 t = mm[sg];
+                                    if (use_tab) {
+                                        const double4 h = hb[i - t0i];
+                                        sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
                                     } else {
-                                        const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
-                                                                    last ? ryL : ry);
-                                        sv = v0 * (1.0 - nt) + v1 * nt;
+                                        const double nt = div_small((double)(i - t0i), stepd, ry);
+                                        const double t2 = nt * nt;
+                                        const double t3 = t2 * nt;
+                                        const double two_t3 = t3 * 2.0;
+                                        const double two_t2 = t2 * 2.0;
+                                        const double three_t2 = t2 * 3.0;
+                                        sv = v0 * (two_t3 - three_t2 + 1.0) + t.x * (t3 - two_t2 + nt) +
+                                             v1 * (three_t2 - two_t3) + t.y * (t3 - t2);
                                     }
-                                }
-                                double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
-                                if (pfast) {
-                                    o = fmin(fmax(o, smin), smax);  // o is finite: same as the compares
                                 } else {
-                                    if (o < smin) o = smin;
-                                    else if (o > smax) o = smax;
+                                    const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                            last ? ryL : ry);
+                                    sv = v0 * (1.0 - nt) + v1 * nt;
                                 }
-                                s += fabs(o - g[m]) * inv[m];
                             }
+                            double o = div1e5(round(sv * 100000.0));  // utils/mod.rs:66-74
+                            if (pfast) {
+                                o = fmin(fmax(o, smin), smax);  // o is finite: same as the compares
+                            } else {
+                                if (o < smin) o = smin;
+                                else if (o > smax) o = smax;
+                            }
+                            return fabs(o - g[m]) * inv[m];
+                        };
+                        // Every term is >= 0 and, with a finite range and no zero sample, finite: the sum
+                        // over one slice of the samples is then a lower bound of the trip's error (floating
+                        // point addition is monotone), and if that alone already fails the trip, nothing the
+                        // other slices add can change the decision.  The first trips of a busy frame end here.
+                        double t1 = 0.0;
+                        bool fails = false;
+                        if (SPL >= 2 && pfast && nozero) {
+                            t1 = term(1);
+                            const double lb = block_sum_f64<W>(t1, red, parity) * inv_n;
+                            if (round(lb * 10000.0) > prm.poly_q_hi) { cur = lb; fails = true; }
                         }
-                        s = block_sum_f64<W>(s, red, parity);
-                        cur = s * inv_n;
+                        if (!fails) {
+                            double s = 0.0;
+#pragma unroll
+                            for (int m = 0; m < SPL; ++m) s += (m == 1 && SPL >= 2 && pfast && nozero) ? t1 : term(m);
+                            s = block_sum_f64<W>(s, red, parity);
+                            cur = s * inv_n;
+                        }
                     }
                     if (poly_trips > 22) {  // polynomial.rs:255-263: the jumps are spent
                         if (round(cur * 10000.0) < prm.poly_q_lo) break;  // target > round(err, 4)
