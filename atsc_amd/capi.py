@@ -71,6 +71,7 @@ SIGNATURES = {
     "atsc_dplan_n_samples": (C.c_uint64, [_vp]),
     "atsc_decompress_plan_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "atsc_decompress_frames": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, _f64p, C.c_uint64, _u64p]),
+    "atsc_decompress_frames_alloc": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, C.POINTER(_f64p), _u64p]),
     "atsc_stream_new": (C.c_int, [_vp, C.POINTER(_vp)]),
     "atsc_stream_from_bytes": (C.c_int, [_vp, _u8p, C.c_uint64, C.POINTER(_vp)]),
     "atsc_stream_free": (None, [_vp]),

@@ -62,6 +62,12 @@ struct atsc_ctx {
     uint64_t diag_n = 0;
     hipStream_t diag_stream = nullptr;
     bool want_diag = false;
+    // Device memory pool.  The host-pointer entry points build a plan and five buffers per call and
+    // drop them at the end; hipMalloc / hipFree of hundreds of megabytes cost milliseconds each, so
+    // freed blocks are kept (up to POOL_MAX_BYTES) and handed out again when the size fits.
+    std::vector<std::pair<void *, size_t>> pool_free_list;
+    std::map<void *, size_t> pool_live;
+    size_t pool_held = 0;
     hipStream_t pack_stream = nullptr;  // created by the first pipelined call
     bool adaptive_order = true;         // pipelined calls start a class's costliest frames first
     int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
@@ -168,6 +174,49 @@ static int fail(atsc_ctx *ctx, int rc, const char *what, hipError_t e = hipSucce
         hipError_t e__ = (call);                                             \
         if (e__ != hipSuccess) return fail((ctx), ATSC_E_HIP, #call, e__);   \
     } while (0)
+
+static const size_t POOL_MAX_BYTES = 8ull << 30;
+static hipError_t pool_alloc(atsc_ctx *ctx, void **out, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    // smallest kept block that fits without wasting more than half of itself (or 4 MB)
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->pool_free_list.size(); ++i) {
+        const size_t sz = ctx->pool_free_list[i].second;
+        if (sz >= bytes && sz <= std::max(2 * bytes, bytes + (4u << 20)) &&
+            (best == (size_t)-1 || sz < ctx->pool_free_list[best].second))
+            best = i;
+    }
+    if (best != (size_t)-1) {
+        *out = ctx->pool_free_list[best].first;
+        ctx->pool_live[*out] = ctx->pool_free_list[best].second;
+        ctx->pool_held -= ctx->pool_free_list[best].second;
+        ctx->pool_free_list.erase(ctx->pool_free_list.begin() + (long)best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->pool_free_list.empty()) {  // give the kept blocks back and retry
+        for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
+        ctx->pool_free_list.clear();
+        ctx->pool_held = 0;
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->pool_live[*out] = bytes;
+    return e;
+}
+// The caller guarantees that no kernel still uses the block (plan destruction synchronises the device
+// once, as hipFree would for every block; the host-pointer entry points have synchronised already).
+static void pool_free(atsc_ctx *ctx, void *p)
+{
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) { (void)hipFree(p); return; }
+    const size_t sz = it->second;
+    ctx->pool_live.erase(it);
+    if (ctx->pool_held + sz > POOL_MAX_BYTES || ctx->pool_free_list.size() >= 256) { (void)hipFree(p); return; }
+    ctx->pool_free_list.emplace_back(p, sz);
+    ctx->pool_held += sz;
+}
 
 static bool is_decomposable(uint64_t n)
 {
@@ -349,18 +398,18 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
 
 static int upload_tables(atsc_ctx *ctx, PlanTables &T)
 {
-    HIPCHK(ctx, hipMalloc((void **)&T.d_plans, std::max<size_t>(1, T.plans.size()) * sizeof(DevPlan)));
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&T.d_plans, std::max<size_t>(1, T.plans.size()) * sizeof(DevPlan)));
     HIPCHK(ctx, hipMemcpy(T.d_plans, T.plans.data(), T.plans.size() * sizeof(DevPlan),
                           hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc((void **)&T.d_tw, std::max<size_t>(1, T.twpool.size()) * sizeof(float2)));
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&T.d_tw, std::max<size_t>(1, T.twpool.size()) * sizeof(float2)));
     HIPCHK(ctx, hipMemcpy(T.d_tw, T.twpool.data(), T.twpool.size() * sizeof(float2),
                           hipMemcpyHostToDevice));
     return ATSC_OK;
 }
-static void free_tables(PlanTables &T)
+static void free_tables(atsc_ctx *ctx, PlanTables &T)
 {
-    if (T.d_plans) (void)hipFree(T.d_plans);
-    if (T.d_tw) (void)hipFree(T.d_tw);
+    pool_free(ctx, T.d_plans);
+    pool_free(ctx, T.d_tw);
     T.d_plans = nullptr;
     T.d_tw = nullptr;
 }
@@ -412,6 +461,8 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
+    for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
+    for (auto &b : ctx->pool_live) (void)hipFree(b.first);  // blocks of plans that outlive their context
     delete ctx;
 }
 extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
@@ -461,39 +512,39 @@ extern "C" int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t 
 // ------------------------------------------------------------------------------------------
 // compress plan
 // ------------------------------------------------------------------------------------------
-static void free_sub(SubPlan *t)
+static void free_sub(atsc_ctx *ctx, SubPlan *t)
 {
     if (!t) return;
-    free_tables(t->tabs);
-    if (t->d_frames) (void)hipFree(t->d_frames);
-    if (t->d_ids) (void)hipFree(t->d_ids);
-    if (t->d_res) (void)hipFree(t->d_res);
+    free_tables(ctx, t->tabs);
+    pool_free(ctx, t->d_frames);
+    pool_free(ctx, t->d_ids);
+    pool_free(ctx, t->d_res);
     delete t;
 }
 
 extern "C" void atsc_plan_destroy(atsc_plan *p)
 {
     if (!p) return;
-    for (int i = 0; i < 7; ++i) free_sub(p->trials[i]);
-    free_sub(p->nopad);
-    free_tables(p->tabs);
-    if (p->d_frames) (void)hipFree(p->d_frames);
-    if (p->d_ids) (void)hipFree(p->d_ids);
-    if (p->d_res) (void)hipFree(p->d_res);
-    if (p->d_slots) (void)hipFree(p->d_slots);
-    if (p->d_local) (void)hipFree(p->d_local);
-    if (p->d_blocksum) (void)hipFree(p->d_blocksum);
-    if (p->d_ws) (void)hipFree(p->d_ws);
-    if (p->ev_pack[0] || p->ev_pack[1]) (void)hipDeviceSynchronize();  // packing may still read the scratch
-    if (p->alt.d_res) (void)hipFree(p->alt.d_res);
-    if (p->alt.d_slots) (void)hipFree(p->alt.d_slots);
-    if (p->alt.d_local) (void)hipFree(p->alt.d_local);
-    if (p->alt.d_blocksum) (void)hipFree(p->alt.d_blocksum);
-    if (p->d_cost) (void)hipFree(p->d_cost);
-    if (p->d_bucket) (void)hipFree(p->d_bucket);
-    if (p->d_hist) (void)hipFree(p->d_hist);
-    if (p->d_ids_adapt[0]) (void)hipFree(p->d_ids_adapt[0]);
-    if (p->d_ids_adapt[1]) (void)hipFree(p->d_ids_adapt[1]);
+    (void)hipDeviceSynchronize();  // as hipFree would: nothing in flight may still use the plan's blocks
+    for (int i = 0; i < 7; ++i) free_sub(p->ctx, p->trials[i]);
+    free_sub(p->ctx, p->nopad);
+    free_tables(p->ctx, p->tabs);
+    pool_free(p->ctx, p->d_frames);
+    pool_free(p->ctx, p->d_ids);
+    pool_free(p->ctx, p->d_res);
+    pool_free(p->ctx, p->d_slots);
+    pool_free(p->ctx, p->d_local);
+    pool_free(p->ctx, p->d_blocksum);
+    pool_free(p->ctx, p->d_ws);
+    pool_free(p->ctx, p->alt.d_res);
+    pool_free(p->ctx, p->alt.d_slots);
+    pool_free(p->ctx, p->alt.d_local);
+    pool_free(p->ctx, p->alt.d_blocksum);
+    pool_free(p->ctx, p->d_cost);
+    pool_free(p->ctx, p->d_bucket);
+    pool_free(p->ctx, p->d_hist);
+    pool_free(p->ctx, p->d_ids_adapt[0]);
+    pool_free(p->ctx, p->d_ids_adapt[1]);
     for (int k = 0; k < 2; ++k) {
         if (p->ev_codec[k]) (void)hipEventDestroy(p->ev_codec[k]);
         if (p->ev_pack[k]) (void)hipEventDestroy(p->ev_pack[k]);
@@ -609,18 +660,18 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
         hipError_t e__ = (call);                                                       \
         if (e__ != hipSuccess) { atsc_plan_destroy(p); return fail(ctx, ATSC_E_HIP, #call, e__); } \
     } while (0)
-    PCHK(hipMalloc((void **)&p->d_frames, n_frames * sizeof(DevFrame)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_frames, n_frames * sizeof(DevFrame)));
     PCHK(hipMemcpy(p->d_frames, frames.data(), n_frames * sizeof(DevFrame), hipMemcpyHostToDevice));
-    PCHK(hipMalloc((void **)&p->d_ids, n_frames * sizeof(uint32_t)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_ids, n_frames * sizeof(uint32_t)));
     PCHK(hipMemcpy(p->d_ids, ids.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice));
-    PCHK(hipMalloc((void **)&p->d_res, n_frames * sizeof(DevResult)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_res, n_frames * sizeof(DevResult)));
     p->slots_bytes = std::max<uint64_t>(slot, 16);
-    PCHK(hipMalloc((void **)&p->d_slots, p->slots_bytes));
-    PCHK(hipMalloc((void **)&p->d_local, n_frames * sizeof(uint32_t)));
-    PCHK(hipMalloc((void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_slots, p->slots_bytes));
+    PCHK(pool_alloc(ctx, (void **)&p->d_local, n_frames * sizeof(uint32_t)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
     if (p->class_count[CLASS_LARGE]) {
         p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
-        PCHK(hipMalloc((void **)&p->d_ws, p->ws_stride * p->ws_slots));
+        PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK
     *out = p;
@@ -654,14 +705,14 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
         uint32_t pi;
         if (it == t->tabs.by_n.end()) {
             int rc = build_plan_entry(n, t->tabs, tw_by_L, nopad);
-            if (rc) { free_sub(t); return fail(ctx, rc, "sub plan entry"); }
+            if (rc) { free_sub(ctx, t); return fail(ctx, rc, "sub plan entry"); }
             pi = t->tabs.by_n[n];
         } else {
             pi = it->second;
         }
         const DevPlan &dp = t->tabs.plans[pi];
         const int c = class_of(n, dp.L);
-        if (c < 0) { free_sub(t); return fail(ctx, ATSC_E_UNSUPPORTED, "sub plan: frame class"); }
+        if (c < 0) { free_sub(ctx, t); return fail(ctx, ATSC_E_UNSUPPORTED, "sub plan: frame class"); }
         fr[f].n = n;
         fr[f].plan = pi;
         sel.push_back((uint32_t)f);
@@ -678,17 +729,17 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
         for (size_t i = 0; i < sel.size(); ++i) ids[cur[cls[i]]++] = sel[i];
         t->large_tiled = choose_large_tiled(t->class_count[CLASS_LARGE]);
         int rc = upload_tables(ctx, t->tabs);
-        if (rc) { free_sub(t); return rc; }
+        if (rc) { free_sub(ctx, t); return rc; }
 #define TCHK(call)                                                                      \
     do {                                                                                \
         hipError_t e__ = (call);                                                        \
-        if (e__ != hipSuccess) { free_sub(t); return fail(ctx, ATSC_E_HIP, #call, e__); } \
+        if (e__ != hipSuccess) { free_sub(ctx, t); return fail(ctx, ATSC_E_HIP, #call, e__); } \
     } while (0)
-        TCHK(hipMalloc((void **)&t->d_frames, fr.size() * sizeof(DevFrame)));
+        TCHK(pool_alloc(ctx, (void **)&t->d_frames, fr.size() * sizeof(DevFrame)));
         TCHK(hipMemcpy(t->d_frames, fr.data(), fr.size() * sizeof(DevFrame), hipMemcpyHostToDevice));
-        TCHK(hipMalloc((void **)&t->d_ids, ids.size() * sizeof(uint32_t)));
+        TCHK(pool_alloc(ctx, (void **)&t->d_ids, ids.size() * sizeof(uint32_t)));
         TCHK(hipMemcpy(t->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (want_res) TCHK(hipMalloc((void **)&t->d_res, fr.size() * sizeof(DevResult)));
+        if (want_res) TCHK(pool_alloc(ctx, (void **)&t->d_res, fr.size() * sizeof(DevResult)));
 #undef TCHK
     }
     *out = t;
@@ -755,16 +806,16 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         if (!ctx->pack_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking));
         if (!plan->alt.d_res) {
             const uint32_t nb = (uint32_t)((plan->n_frames + 1023) / 1024);
-            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_res, plan->n_frames * sizeof(DevResult)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_slots, plan->slots_bytes));
-            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_local, plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->alt.d_blocksum, (nb + 1) * sizeof(uint64_t)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->d_cost, plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_res, plan->n_frames * sizeof(DevResult)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_slots, plan->slots_bytes));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_local, plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_blocksum, (nb + 1) * sizeof(uint64_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_cost, plan->n_frames * sizeof(uint32_t)));
             HIPCHK(ctx, hipMemset(plan->d_cost, 0, plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->d_bucket, plan->n_frames));
-            HIPCHK(ctx, hipMalloc((void **)&plan->d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->d_ids_adapt[0], plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, hipMalloc((void **)&plan->d_ids_adapt[1], plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_bucket, plan->n_frames));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ids_adapt[0], plan->n_frames * sizeof(uint32_t)));
+            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ids_adapt[1], plan->n_frames * sizeof(uint32_t)));
             for (int i = 0; i < 2; ++i) {
                 // ev_codec rides on the last k_compress dispatch (hipExtLaunchKernel stop event)
                 HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_codec[i], hipEventReleaseToDevice));
@@ -1003,11 +1054,11 @@ extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const 
         e = (call);                                           \
         if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
     } while (0)
-    FCHK(hipMalloc((void **)&d_x, ns * sizeof(double)));
-    FCHK(hipMalloc((void **)&d_body, std::max<uint64_t>(bound, 16)));
-    FCHK(hipMalloc((void **)&d_off, (n_frames + 1) * sizeof(uint64_t)));
-    FCHK(hipMalloc((void **)&d_ch, n_frames));
-    FCHK(hipMalloc((void **)&d_err, n_frames * sizeof(double)));
+    FCHK(pool_alloc(ctx, (void **)&d_x, ns * sizeof(double)));
+    FCHK(pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(bound, 16)));
+    FCHK(pool_alloc(ctx, (void **)&d_off, (n_frames + 1) * sizeof(uint64_t)));
+    FCHK(pool_alloc(ctx, (void **)&d_ch, n_frames));
+    FCHK(pool_alloc(ctx, (void **)&d_err, n_frames * sizeof(double)));
     FCHK(hipMemcpy(d_x, samples + frame_off[0], ns * sizeof(double), hipMemcpyHostToDevice));
     rc = atsc_compress_plan_dev(ctx, plan, d_x, compressor, bounded, max_error, sample_level, d_body,
                                 bound, d_off, d_ch, d_err, nullptr);
@@ -1022,11 +1073,11 @@ extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const 
     if (err) FCHK(hipMemcpy(err, d_err, n_frames * sizeof(double), hipMemcpyDeviceToHost));
 #undef FCHK
 done:
-    if (d_x) (void)hipFree(d_x);
-    if (d_body) (void)hipFree(d_body);
-    if (d_off) (void)hipFree(d_off);
-    if (d_ch) (void)hipFree(d_ch);
-    if (d_err) (void)hipFree(d_err);
+    pool_free(ctx, d_x);
+    pool_free(ctx, d_body);
+    pool_free(ctx, d_off);
+    pool_free(ctx, d_ch);
+    pool_free(ctx, d_err);
     atsc_plan_destroy(plan);
     return rc;
 }
@@ -1115,11 +1166,12 @@ extern "C" int atsc_bro_open(const uint8_t *bro, uint64_t len, uint64_t *body_of
 extern "C" void atsc_dplan_destroy(atsc_dplan *p)
 {
     if (!p) return;
-    free_tables(p->tabs);
-    if (p->d_frames) (void)hipFree(p->d_frames);
-    if (p->d_ids) (void)hipFree(p->d_ids);
-    if (p->d_status) (void)hipFree(p->d_status);
-    if (p->d_ws) (void)hipFree(p->d_ws);
+    (void)hipDeviceSynchronize();
+    free_tables(p->ctx, p->tabs);
+    pool_free(p->ctx, p->d_frames);
+    pool_free(p->ctx, p->d_ids);
+    pool_free(p->ctx, p->d_status);
+    pool_free(p->ctx, p->d_ws);
     delete p;
 }
 extern "C" uint64_t atsc_dplan_n_frames(const atsc_dplan *p) { return p ? p->n_frames : 0; }
@@ -1210,15 +1262,15 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         hipError_t e__ = (call);                                                        \
         if (e__ != hipSuccess) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_HIP, #call, e__); } \
     } while (0)
-    PCHK(hipMalloc((void **)&p->d_frames, frames.size() * sizeof(DevDFrame)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_frames, frames.size() * sizeof(DevDFrame)));
     PCHK(hipMemcpy(p->d_frames, frames.data(), frames.size() * sizeof(DevDFrame), hipMemcpyHostToDevice));
-    PCHK(hipMalloc((void **)&p->d_ids, ids.size() * sizeof(uint32_t)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_ids, ids.size() * sizeof(uint32_t)));
     PCHK(hipMemcpy(p->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    PCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
+    PCHK(pool_alloc(ctx, (void **)&p->d_status, sizeof(int)));
     PCHK(hipMemset(p->d_status, 0, sizeof(int)));
     if (p->class_count[CLASS_LARGE]) {
         p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
-        PCHK(hipMalloc((void **)&p->d_ws, p->ws_stride * p->ws_slots));
+        PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK
     *out = p;
@@ -1246,15 +1298,22 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
     return ATSC_OK;
 }
 
-extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
-                                      int has_count, double *out, uint64_t out_cap, uint64_t *out_n)
+// out == nullptr: *out_alloc receives a malloc'd buffer of exactly the decoded length (atsc_free)
+static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
+                                  double *out, uint64_t out_cap, double **out_alloc, uint64_t *out_n)
 {
-    if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
     atsc_dplan *dp = nullptr;
     int rc = atsc_dplan_create(ctx, body, body_len, has_count, &dp);
     if (rc) return rc;
     *out_n = dp->n_samples;
-    if (dp->n_samples > out_cap) { atsc_dplan_destroy(dp); return fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap"); }
+    double *host = out;
+    if (!out) {
+        host = (double *)malloc((dp->n_samples ? dp->n_samples : 1) * sizeof(double));
+        if (!host) { atsc_dplan_destroy(dp); return fail(ctx, ATSC_E_NOMEM, "decompress_frames: output"); }
+    } else if (dp->n_samples > out_cap) {
+        atsc_dplan_destroy(dp);
+        return fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap");
+    }
     uint8_t *d_body = nullptr;
     double *d_out = nullptr;
     int status = 0;
@@ -1264,19 +1323,36 @@ extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64
         e = (call);                                           \
         if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
     } while (0)
-    FCHK(hipMalloc((void **)&d_body, std::max<uint64_t>(body_len, 16)));
-    FCHK(hipMalloc((void **)&d_out, dp->n_samples * sizeof(double)));
+    FCHK(pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(body_len, 16)));
+    FCHK(pool_alloc(ctx, (void **)&d_out, dp->n_samples * sizeof(double)));
     FCHK(hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice));
     rc = atsc_decompress_plan_dev(ctx, dp, d_body, d_out, nullptr);
     if (rc) goto done;
     FCHK(hipStreamSynchronize(nullptr));
     FCHK(hipMemcpy(&status, dp->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (status) { rc = fail(ctx, ATSC_E_FORMAT, "decompress_frames: malformed payload"); goto done; }
-    FCHK(hipMemcpy(out, d_out, dp->n_samples * sizeof(double), hipMemcpyDeviceToHost));
+    FCHK(hipMemcpy(host, d_out, dp->n_samples * sizeof(double), hipMemcpyDeviceToHost));
 #undef FCHK
 done:
-    if (d_body) (void)hipFree(d_body);
-    if (d_out) (void)hipFree(d_out);
+    pool_free(ctx, d_body);
+    pool_free(ctx, d_out);
     atsc_dplan_destroy(dp);
+    if (!out) {
+        if (rc) free(host);
+        else *out_alloc = host;
+    }
     return rc;
+}
+extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
+                                      int has_count, double *out, uint64_t out_cap, uint64_t *out_n)
+{
+    if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
+    return decompress_frames_impl(ctx, body, body_len, has_count, out, out_cap, nullptr, out_n);
+}
+extern "C" int atsc_decompress_frames_alloc(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
+                                            int has_count, double **out, uint64_t *out_n)
+{
+    if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames_alloc: null argument");
+    *out = nullptr;
+    return decompress_frames_impl(ctx, body, body_len, has_count, nullptr, 0, out, out_n);
 }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -130,17 +131,19 @@ static int flush(atsc_stream *s)
             memcpy(flat.data() + off[k], c.data(), c.size() * sizeof(double));
             cap += atsc_payload_bound_bytes(c.size()) + 16;
         }
-        std::vector<uint8_t> body(cap);
+        // worst-case capacity, never touched beyond the bytes that come back: no zero fill
+        std::unique_ptr<uint8_t[]> body(new (std::nothrow) uint8_t[cap ? cap : 1]);
+        if (!body) return ATSC_E_NOMEM;
         std::vector<uint64_t> rec_off(idx.size() + 1);
         uint64_t blen = 0;
         const Item &first = s->items[idx[0]];
         int rc = atsc_compress_frames(s->ctx, flat.data(), off.data(), idx.size(), first.compressor,
-                                      first.bounded, first.max_error, first.level, body.data(), cap, &blen,
+                                      first.bounded, first.max_error, first.level, body.get(), cap, &blen,
                                       rec_off.data(), nullptr, nullptr);
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) {
             Item &it = s->items[idx[k]];
-            it.record.assign(body.begin() + rec_off[k], body.begin() + rec_off[k + 1]);
+            it.record.assign(body.get() + rec_off[k], body.get() + rec_off[k + 1]);
             it.pending = false;
             std::vector<double>().swap(it.chunk);
         }
@@ -236,37 +239,71 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
                                   uint8_t error_pct, int sample_level, uint8_t **bro, uint64_t *len)
 {
     if (!ctx || (!data && n) || !bro || !len) return ATSC_E_INVALID;
-    std::vector<double> clean(n ? n : 1);
-    const uint64_t cn = atsc_clean_data(data, n, clean.data());          // optimizer/mod.rs:47-49
+    *bro = nullptr;
+    *len = 0;
+    if (compressor < 0 || compressor > 6 || sample_level < 0 || sample_level > 6) return ATSC_E_INVALID;
+    // OptimizerPlan::plan drops NaN and infinite samples (optimizer/mod.rs:47-49); the copy is only
+    // made when there is something to drop
+    bool dirty = false;
+    for (uint64_t i = 0; i < n && !dirty; ++i) dirty = !std::isfinite(data[i]);
+    std::vector<double> clean;
+    const double *src = data;
+    uint64_t cn = n;
+    if (dirty) {
+        clean.resize(n);
+        cn = atsc_clean_data(data, n, clean.data());
+        src = clean.data();
+    }
     const uint64_t nch = atsc_chunk_sizes(cn, nullptr, 0);
-    std::vector<uint64_t> sizes(nch ? nch : 1);
+    if (nch == 0) {  // an empty stream: header + count 0 (data.rs:79-85)
+        uint8_t *buf = (uint8_t *)malloc(18);
+        if (!buf) return ATSC_E_NOMEM;
+        *len = atsc_bro_prefix(0, buf);
+        *bro = buf;
+        return ATSC_OK;
+    }
+    std::vector<uint64_t> sizes(nch), off(nch + 1, 0);
     atsc_chunk_sizes(cn, sizes.data(), nch);
-    atsc_stream *s = nullptr;
-    int rc = atsc_stream_new(ctx, &s);
-    if (rc) return rc;
+    uint64_t cap = 0;
+    for (uint64_t c = 0; c < nch; ++c) {
+        off[c + 1] = off[c] + sizes[c];
+        cap += atsc_payload_bound_bytes(sizes[c]) + 16;
+    }
+    // main.rs:146-163: every chunk of the plan goes through the same call, bounded for the lossy
+    // codecs and Auto, plain otherwise -- one batch for the GPU, written behind the stream prefix
     const bool lossy = compressor == ATSC_FFT || compressor == ATSC_POLYNOMIAL || compressor == ATSC_IDW ||
                        compressor == ATSC_AUTO;                            // main.rs:150-162
-    const float max_error = (float)error_pct / 100.0f;                     // main.rs:157
-    uint64_t off = 0;
-    for (uint64_t c = 0; c < nch && !rc; ++c) {
-        rc = lossy ? atsc_stream_compress_chunk_bounded_with(s, clean.data() + off, sizes[c], compressor,
-                                                             max_error, sample_level)
-                   : atsc_stream_compress_chunk_with(s, clean.data() + off, sizes[c], compressor);
-        off += sizes[c];
-    }
-    if (!rc) rc = atsc_stream_to_bytes(s, bro, len);
-    atsc_stream_free(s);
-    return rc;
+    const float max_error = lossy ? (float)error_pct / 100.0f : 0.0f;      // main.rs:157
+    uint8_t *buf = (uint8_t *)malloc(18 + cap);  // worst case; only the bytes produced are touched
+    if (!buf) return ATSC_E_NOMEM;
+    const uint64_t pre = atsc_bro_prefix(nch, buf);
+    uint64_t blen = 0;
+    int rc = atsc_compress_frames(ctx, src, off.data(), nch, compressor, lossy ? 1 : 0, max_error,
+                                  lossy ? sample_level : 0, buf + pre, cap, &blen, nullptr, nullptr, nullptr);
+    if (rc) { free(buf); return rc; }
+    uint8_t *fit = (uint8_t *)realloc(buf, pre + blen);
+    *bro = fit ? fit : buf;
+    *len = pre + blen;
+    return ATSC_OK;
 }
 
 extern "C" int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, double **out, uint64_t *n)
 {
-    atsc_stream *s = nullptr;
-    int rc = atsc_stream_from_bytes(ctx, bro, len, &s);
+    if (!ctx || !bro || !out || !n) return ATSC_E_INVALID;
+    *out = nullptr;
+    *n = 0;
+    uint64_t body_off = 0, n_frames = 0;
+    int rc = atsc_bro_open(bro, len, &body_off, &n_frames);  // data.rs:89-97, header.rs:69-84
     if (rc) return rc;
-    rc = atsc_stream_decompress(s, out, n);
-    atsc_stream_free(s);
-    return rc;
+    if (n_frames == 0) {
+        *out = (double *)malloc(8);
+        return *out ? ATSC_OK : ATSC_E_NOMEM;
+    }
+    // The records go to the GPU as they lie in the file, from the frame-count varint (offset 9, right
+    // after the header) on: exactly that many records are decoded and anything behind them is ignored,
+    // as bincode's decode_from_slice does (data.rs:98); the output is sized by the decoder.
+    (void)body_off;
+    return atsc_decompress_frames_alloc(ctx, bro + 9, len - 9, 1, out, n);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -61,8 +61,8 @@ class Context:
         x = np.ascontiguousarray(np.asarray(samples, dtype=np.float64))
         off, poff = _u64(frame_off)
         nf = len(off) - 1
-        cap = sum(int(capi.lib().atsc_payload_bound_bytes(int(off[i + 1] - off[i]))) + 16
-                  for i in range(nf))
+        lens = np.diff(off.astype(np.int64))
+        cap = int(np.sum(48 + np.where(lens > 65535, 17, 14) * lens))  # sum of atsc_payload_bound_bytes + 16
         body = np.empty(max(cap, 16), dtype=np.uint8)
         blen = C.c_uint64()
         rec = np.zeros(nf + 1, dtype=np.uint64)

@@ -184,6 +184,10 @@ int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t 
 /* Host-pointer convenience (synchronous). out_n receives the sample count. */
 int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
                            double *out, uint64_t out_cap, uint64_t *out_n);
+/* The same with the output allocated by the library at exactly the decoded length (atsc_free):
+ * what CompressedStream::decompress returns (data.rs:104-109), without a sizing pass by the caller. */
+int atsc_decompress_frames_alloc(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
+                                 double **out, uint64_t *out_n);
 
 /* ------------------------------------------------------------------------ */
 /* CompressedStream mirror (atsc/src/data.rs:29-110)                          */
