@@ -462,7 +462,8 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
     for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
-    for (auto &b : ctx->pool_live) (void)hipFree(b.first);  // blocks of plans that outlive their context
+    // blocks still held by plans that outlive their context (a contract violation) are left alone: their
+    // owners would otherwise free them a second time
     delete ctx;
 }
 extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)

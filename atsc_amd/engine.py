@@ -1,6 +1,7 @@
 """Thin Python plumbing over the C ABI: device memory and streams come from PyTorch-ROCm,
 everything else happens inside libatsc_hip.so.  No compression logic lives here."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -19,9 +20,12 @@ class Context:
         self._h = C.c_void_p()
         capi.check(capi.lib().atsc_ctx_create(C.byref(self._h), int(device)))
         self.device = int(device)
+        self._children = weakref.WeakSet()  # plans own device blocks of this context's pool
 
     def close(self):
         if self._h:
+            for ch in list(self._children):  # plans go first: atsc_ctx_destroy releases the pool
+                ch.close()
             capi.lib().atsc_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -106,6 +110,7 @@ class Plan:
         self.n_frames = int(capi.lib().atsc_plan_n_frames(self._h))
         self.n_samples = int(capi.lib().atsc_plan_n_samples(self._h))
         self.body_bound = int(capi.lib().atsc_plan_body_bound(self._h))
+        ctx._children.add(self)
 
     def close(self):
         if self._h:
@@ -160,6 +165,7 @@ class DPlan:
             int(has_count), C.byref(self._h)), ctx._h)
         self.n_frames = int(capi.lib().atsc_dplan_n_frames(self._h))
         self.n_samples = int(capi.lib().atsc_dplan_n_samples(self._h))
+        ctx._children.add(self)
 
     def close(self):
         if self._h:

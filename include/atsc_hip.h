@@ -72,6 +72,8 @@ const char *atsc_version(void);
 /* Creates a context on HIP device `device` (0-based).  Fails with
  * ATSC_E_NO_DEVICE when there is no GPU: there is no CPU fallback. */
 int atsc_ctx_create(atsc_ctx **out, int device);
+/* Plans, decode plans and streams created on a context hold device memory of its pool: destroy them
+ * before the context. */
 void atsc_ctx_destroy(atsc_ctx *ctx);
 const char *atsc_ctx_last_error(const atsc_ctx *ctx);
 
