@@ -775,3 +775,38 @@ def test_compress_is_graph_capturable(ctx, A):
         g.replay()
         torch.cuda.synchronize()
         assert fetch() == want[i], i
+
+
+@pytest.mark.parametrize("comp,bounded,level", [("AUTO", True, 3), ("AUTO", True, 6), ("FFT", False, 0),
+                                                ("RLE", False, 0), ("POLYNOMIAL", True, 0), ("IDW", True, 0)])
+def test_pipelined_modes_match_plain_calls(ctx, A, comp, bounded, level):
+    """The pipelined entry point with the sample-level trial launch, the unpadded-FFT sub-plan and
+    forced codecs: four batches back-to-back give the bytes of plain calls."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    lens = [256] * 300 + [1024] * 24 + [4096] * 6 + [8192] * 2 + [200] * 30
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(off[-1])
+    plan = ctx.plan(off)
+    stream = torch.cuda.current_stream().cuda_stream
+    cid = getattr(A, comp)
+    data = [torch.from_numpy(H.synth_series(600 + b, n, block=2048)).to(dev) for b in range(2)]
+
+    def fetch(o):
+        total = int(o["rec_off"][-1].item())
+        return o["body"][:total].cpu().numpy().tobytes()
+
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for d_x in data:
+        plan.compress(d_x, o, cid, bounded, ME5, level, stream)
+        torch.cuda.synchronize()
+        ref.append(fetch(o))
+    outs = [plan.alloc_outputs(torch, dev) for _ in range(4)]
+    for b in range(4):
+        plan.compress(data[b % 2], outs[b], cid, bounded, ME5, level, stream, pipelined=True)
+    plan.join(stream)
+    torch.cuda.current_stream().synchronize()
+    for b in range(4):
+        assert fetch(outs[b]) == ref[b % 2], (comp, b)
