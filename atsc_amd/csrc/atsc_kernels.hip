@@ -1535,7 +1535,11 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
 {
     if (count == 0) return hipSuccess;
     auto kern = k_compress<W, SPL, IDW, FN>;
-    if (const char *pad = getenv("ATSC_DEBUG_LDS_PAD")) lds += (uint32_t)atoi(pad);  // occupancy experiments only
+    static const uint32_t lds_pad = [] {  // ATSC_DEBUG_LDS_PAD: occupancy experiments only, read once
+        const char *pad = getenv("ATSC_DEBUG_LDS_PAD");
+        return pad ? (uint32_t)atoi(pad) : 0u;
+    }();
+    lds += lds_pad;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
