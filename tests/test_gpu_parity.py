@@ -810,3 +810,25 @@ def test_pipelined_modes_match_plain_calls(ctx, A, comp, bounded, level):
     torch.cuda.current_stream().synchronize()
     for b in range(4):
         assert fetch(outs[b]) == ref[b % 2], (comp, b)
+
+
+def test_host_entry_points_reuse_device_memory(ctx, A):
+    """The host-pointer entry points build a plan and their buffers per call; the context's pool hands
+    the same device blocks out again, so repeated calls do not grow the footprint, and results repeat."""
+    import torch
+
+    x = H.synth_series(21, 600000)
+    off = H.frame_offsets(len(x), 256)
+    first = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+    bro = A.compress_data(ctx, x, A.AUTO, 5)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        again = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+        assert again[0] == first[0]
+        assert A.compress_data(ctx, x, A.AUTO, 5) == bro
+        out = A.decompress_data(ctx, bro)
+        assert len(out) == len(x)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
