@@ -5,7 +5,7 @@ Bars (north_star / SURVEY 8):
   * FFT payloads: complex-f32 arithmetic that is not bit-reproducible even between two CPUs
     running the reference (rustfft picks its SIMD path at run time).  Same ladder trip count,
     same number of stored bins, same bin positions in the same order, coefficients within
-    FFT_COEF_RTOL of the frame's largest bin, reported error within FFT_ERR_ATOL.
+    FFT_COEF_RTOL of the frame's largest bin, reported error within FFT_ERR_ATOL + FFT_ERR_RTOL * error.
   * A frame whose oracle error sits within BOUNDARY_EPS of a ladder/selector threshold may
     legitimately stop one trip apart (f32 noise crossing the threshold); such frames are
     counted separately and must be rare (< BOUNDARY_FRAC of the batch).
@@ -15,7 +15,8 @@ import numpy as np
 from tests import helpers as H
 
 FFT_COEF_RTOL = 4e-6     # relative to the largest |bin| of the frame (~32 f32 ulp)
-FFT_ERR_ATOL = 2e-6      # absolute, on MAPE
+FFT_ERR_ATOL = 5e-6      # absolute, on MAPE: f32 transform noise plus one 5-decimal rounding flip on a short frame
+FFT_ERR_RTOL = 2e-6      # relative, for the large MAPE values of frames with near-zero samples (noise / |g|)
 POLY_ERR_RTOL = 1e-11    # summation order only
 BOUNDARY_EPS = 5e-6
 BOUNDARY_FRAC = 0.002
@@ -121,7 +122,7 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
             summary[verdict] += 1
             if verdict != "boundary":
                 # reported error: exact codecs report 0.0; lossy within tolerance
-                tol = FFT_ERR_ATOL if tag == oracle.FFT else max(POLY_ERR_RTOL * abs(eo), 1e-300)
+                tol = (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo)) if tag == oracle.FFT else max(POLY_ERR_RTOL * abs(eo), 1e-300)
                 if not (err[i] == eo or abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
                     summary["fail"].append((i, "FAIL:err gpu=%r oracle=%r" % (err[i], eo)))
     return summary
