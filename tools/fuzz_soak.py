@@ -21,8 +21,9 @@ for seed in seeds:
     me = float(np.float32(e) / np.float32(100))
     uniform = seed % 3 == 0
     xs, offs = [], [0]
-    for _ in range(200):
-        n = 256 if uniform else int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, 1024, 2048, 4096,
+    large = os.environ.get("FUZZ_LARGE") == "1"  # frames of the large tier instead (fewer of them)
+    for _ in range(40 if large else 200):
+        n = int(rng.choice([4097, 5000, 6561, 8192, 12000, 20000, 32768, 40000])) if large else 256 if uniform else int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, 1024, 2048, 4096,
                                                 rng.integers(600, 4097)], p=[0.1, 0.35, 0.15, 0.05, 0.05, 0.05, 0.05, 0.05, 0.15]))
         xs.append(_fuzz_frame(rng, n))
         offs.append(offs[-1] + n)
@@ -32,7 +33,7 @@ for seed in seeds:
     s = P.compare_batch(orc, ctx, x, off, comp, bounded, me)
     for k in ("exact", "tol", "boundary"):
         tot[k] += s[k]
-    tot["frames"] += 200
+    tot["frames"] += len(offs) - 1
     line = "seed %d e=%d comp=%d uniform=%d exact=%d tol=%d boundary=%d fail=%d" % (
         seed, e, comp, uniform, s["exact"], s["tol"], s["boundary"], len(s["fail"]))
     print(line, flush=True)
