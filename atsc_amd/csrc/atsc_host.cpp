@@ -31,7 +31,7 @@ uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, hipStream_t s);
+                                   uint32_t ws_slots, int tiled, hipStream_t s, const LargePre *pre = nullptr);
 hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
                                 uint32_t *hist_cursor, const uint32_t *class_first,
                                 const uint32_t *class_count, int n_classes, hipStream_t s);
@@ -153,6 +153,7 @@ struct atsc_dplan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;
+    LargePre large_pre{0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1256,6 +1257,14 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         for (size_t f = 0; f < frames.size(); ++f) ids[cur[cls[f]]++] = (uint32_t)f;
     }
     p->large_tiled = choose_large_tiled(p->class_count[CLASS_LARGE]);
+    if (p->class_count[CLASS_LARGE]) {
+        std::vector<uint32_t> lp;
+        for (size_t f = 0; f < frames.size(); ++f)
+            if (cls[f] == CLASS_LARGE) lp.push_back(frames[f].plan);
+        std::sort(lp.begin(), lp.end());
+        lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
+        p->large_pre = large_pre_extents(p->tabs.plans, lp);
+    }
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_dplan_destroy(p); return rc; }
 #define PCHK(call)                                                                      \
@@ -1289,7 +1298,8 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
         if (c == CLASS_LARGE)
             e = launch_decompress_large(dp->class_count[c], dp->d_frames, dp->d_ids + dp->class_first[c],
                                         dp->tabs.d_plans, dp->tabs.d_tw, d_body, d_out, dp->d_status,
-                                        dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0, s);
+                                        dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0, s,
+                                        dp->large_pre.tiles1 ? &dp->large_pre : nullptr);
         else
             e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
                                   dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,

@@ -372,21 +372,32 @@ struct PreFrame {
     unsigned char *ws;
     uint32_t n, L, M, pre, half, M1, M2, sc, bins;
 };
-DEVI PreFrame pre_frame(const double *samples, const DevFrame *frames, const uint32_t *ids,
+DEVI const double *frame_samples(const double *samples, const DevFrame &fr) { return samples + fr.sample_off; }
+DEVI const double *frame_samples(const double *, const DevDFrame &) { return nullptr; }  // decoder: no samples
+template <class FR>
+DEVI PreFrame pre_frame(const double *samples, const FR *frames, const uint32_t *ids,
                         const DevPlan *plans, unsigned char *ws_base, uint64_t ws_stride, const DevPlan *&P)
 {
-    const DevFrame fr = frames[ids[blockIdx.y]];
+    const FR fr = frames[ids[blockIdx.y]];
     P = &plans[fr.plan];
     PreFrame f;
-    f.xs = samples + fr.sample_off;
+    f.xs = frame_samples(samples, fr);
     f.ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
     f.n = fr.n; f.L = P->L; f.M = P->M; f.pre = P->pre; f.half = P->half;
     f.M1 = P->f4_m1; f.M2 = P->f4_m2; f.sc = P->sc; f.bins = P->bins;
     return f;
 }
-// pass 1: FB columns of the packed (even L) or complex (odd L) padded f32 signal
+// State a large frame's decoder leaves for the batched inverse transform (workspace, o_cnt)
+struct DecPending {
+    uint32_t pending;  // 1: the conjugated packed spectrum waits in buffer A
+    float mxf, mnf;
+    uint32_t pad;
+};
+// pass 1: FB columns of the packed (even L) or complex (odd L) padded f32 signal.  FROM_WS: the
+// input is what the decoder left in buffer A (frames without a pending transform are skipped).
+template <class FR, bool FROM_WS>
 __global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ samples,
-                                                    const DevFrame *__restrict__ frames,
+                                                    const FR *__restrict__ frames,
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
                                                     const float2 *__restrict__ twpool,
@@ -399,7 +410,12 @@ __global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ sa
     if (c0 >= f.M2) return;
     const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
     float2 *Y = (float2 *)(f.ws + lay.o_b);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t *)(f.ws + lay.o_cnt) = 0;
+    const float2 *Xin = (const float2 *)(f.ws + lay.o_a);
+    if (FROM_WS) {
+        if (((const DecPending *)(f.ws + lay.o_cnt))->pending == 0) return;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *(uint32_t *)(f.ws + lay.o_cnt) = 0;
+    }
     const float2 *tw = twpool + P->tw_off;
     float2 *T = (float2 *)smem, *U = T + FB * f.M1, *w1 = U + FB * f.M1;
     for (uint32_t e = threadIdx.x; e < f.M1; e += PT) w1[e] = tw[e * (f.M2 * f.sc)];
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ sa
         const uint32_t c = w & (FB - 1), n1 = w >> 4;
         if (c < nseq) {
             const uint32_t i = f.M2 * n1 + c0 + c;
-            T[n1 * FB + c] = f.half ? make_float2(g(2 * i), g(2 * i + 1)) : make_float2(g(i), 0.0f);
+            T[n1 * FB + c] = FROM_WS ? Xin[i] : f.half ? make_float2(g(2 * i), g(2 * i + 1)) : make_float2(g(i), 0.0f);
         }
     }
     __syncthreads();
@@ -427,8 +443,9 @@ __global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ sa
     }
 }
 // pass 2: FB rows
+template <class FR, bool FROM_WS>
 __global__ __launch_bounds__(PT) void k_large_pre2(const double *__restrict__ samples,
-                                                    const DevFrame *__restrict__ frames,
+                                                    const FR *__restrict__ frames,
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
                                                     const float2 *__restrict__ twpool,
@@ -440,6 +457,7 @@ __global__ __launch_bounds__(PT) void k_large_pre2(const double *__restrict__ sa
     const uint32_t r0 = blockIdx.x * FB;
     if (r0 >= f.M1) return;
     const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
+    if (FROM_WS && ((const DecPending *)(f.ws + lay.o_cnt))->pending == 0) return;
     const float2 *Y = (const float2 *)(f.ws + lay.o_b);
     float2 *X = (float2 *)(f.ws + lay.o_a);
     const float2 *tw = twpool + P->tw_off;
@@ -1312,18 +1330,18 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     if (kp.prefft) {
         lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
         lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
-        e = hipFuncSetAttribute((const void *)k_large_pre1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        e = hipFuncSetAttribute((const void *)k_large_pre1<DevFrame, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)k_large_pre2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        e = hipFuncSetAttribute((const void *)k_large_pre2<DevFrame, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
     }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
         if (kp.prefft) {
-            hipLaunchKernelGGL(k_large_pre1, dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames, ids + b0,
-                               plans, twpool, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_pre2, dim3(pre->tiles2, nb), dim3(PT), lds2, s, samples, frames, ids + b0,
-                               plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames,
+                               ids + b0, plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL((k_large_pre2<DevFrame, false>), dim3(pre->tiles2, nb), dim3(PT), lds2, s, samples, frames,
+                               ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL(k_large_pre3, dim3(pre->chunks, nb), dim3(PT3), 0, s, samples, frames, ids + b0,
                                plans, twpool, ws, ws_stride);
         }
@@ -1339,6 +1357,11 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
 // --------------------------------------------------------------------------------------------
 // k_decompress_large: CompressorFrame::decompress for frames of 4097 .. 131072 samples
 // --------------------------------------------------------------------------------------------
+// PH 0: the whole decoder.  PH 1 / PH 2: the decoder around the batched inverse transform -- PH 1 parses,
+// decodes every codec but FFT completely and leaves an FFT frame's conjugated packed spectrum in buffer A
+// (DecPending in the workspace); k_large_pre1 / k_large_pre2 <DevDFrame, true> transform all pending frames
+// over the whole GPU; PH 2 scales, rounds and clamps.
+template <int PH>
 __global__ __launch_bounds__(LT) void k_decompress_large(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
@@ -1371,6 +1394,31 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     uint64_t *keys = (uint64_t *)(ws + lay.o_rec);  // RLE (start << 32 | group)
     const float2 *tw = twpool + P.tw_off;
     (void)wsum;
+    DecPending *pend = (DecPending *)(ws + lay.o_cnt);
+    if (PH == 2) {  // second half: only frames whose transform was pending
+        if (fr.tag != ATSC_FFT || pend->pending == 0) return;
+        const float mxf = pend->mxf, mnf = pend->mnf;
+        const float2 *F = A;
+        const double mxd = (double)mxf, mnd = (double)mnf;
+        const float Lf = (float)L;
+        for (uint32_t i = tid; i < n; i += T) {
+            const uint32_t j = i + pre;
+            float re;
+            if (P.half) {
+                const float2 f = F[j >> 1];
+                re = 2.0f * ((j & 1) ? -f.y : f.x);
+            } else {
+                re = F[j].x;
+            }
+            const float v = re / Lf;
+            double o = round((double)v * 100000.0) / 100000.0;
+            if (o > mxd) o = mxd;
+            if (o < mnd) o = mnd;
+            out[i] = o;
+        }
+        return;
+    }
+    if (PH == 1 && tid == 0) pend->pending = 0;
 
     // fixed-width point arrays (U8 / F64) are read in parallel after the header; the spectrum must be
     // empty before lane 0 starts filling it
@@ -1563,6 +1611,10 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             }
         }
         __syncthreads();
+        if (PH == 1) {  // the batched kernels take it from here
+            if (tid == 0) { pend->mxf = mxf; pend->mnf = mnf; pend->pending = 1; }
+            return;
+        }
         F = fft_large(P, A, Cb, tw, (float2 *)(smem + 256), tiled != 0);
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
@@ -1603,18 +1655,42 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
 hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, hipStream_t s)
+                                   uint32_t ws_slots, int tiled, hipStream_t s, const LargePre *pre)
 {
     // 256 B of header scratch + the tile buffers of the LDS-tiled inverse transform
     const uint32_t lds = 256 + (2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2);
-    hipError_t ea = hipFuncSetAttribute((const void *)k_decompress_large,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ea != hipSuccess) return ea;
+    const bool split = pre && pre->tiles1;
+    hipError_t e;
+    uint32_t lds1 = 0, lds2 = 0;
+    if (split) {
+        lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
+        lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
+        e = hipFuncSetAttribute((const void *)k_large_pre1<DevDFrame, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_large_pre2<DevDFrame, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+    } else {
+        e = hipFuncSetAttribute((const void *)k_decompress_large<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
-        hipLaunchKernelGGL(k_decompress_large, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                           body, out, status, ws, ws_stride, tiled);
-        hipError_t e = hipGetLastError();
+        if (split) {
+            // parse + every codec but the FFT transform; the transform of all pending frames over the whole
+            // GPU; scale / round / clamp
+            hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
+                               body, out, status, ws, ws_stride, tiled);
+            hipLaunchKernelGGL((k_large_pre1<DevDFrame, true>), dim3(pre->tiles1, nb), dim3(PT), lds1, s,
+                               (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL((k_large_pre2<DevDFrame, true>), dim3(pre->tiles2, nb), dim3(PT), lds2, s,
+                               (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_decompress_large<2>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
+                               body, out, status, ws, ws_stride, tiled);
+        } else {
+            hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
+                               body, out, status, ws, ws_stride, tiled);
+        }
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -10,9 +10,9 @@ me = float(np.float32(5) / np.float32(100))
 dev = torch.device("cuda:0")
 ctx = atsc_amd.Context(0)
 st = torch.cuda.current_stream().cuda_stream
-for nf in (16, 80, 256, 512):
+for nf, klass in ((16, 0), (16, 1), (16, 2), (16, 3), (16, None), (80, None), (256, None), (512, None)):
     n = nf * F
-    x = H.synth_series(3, n, klass=None)
+    x = H.synth_series(3, n, klass=klass)
     off = H.frame_offsets(n, F)
     rec, _, chosen, _ = ctx.compress_host(x, off, atsc_amd.AUTO, True, me, 0)
     dp = atsc_amd.DPlan(ctx, rec)
@@ -26,6 +26,6 @@ for nf in (16, 80, 256, 512):
         dp.decompress(d_body, d_out, st)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("frames %4d  decode %8.2f ms  %7.2f Gsamples/s  codecs %s" % (
-        nf, dt * 1e3, n / dt / 1e9, {int(c): int(np.sum(chosen == c)) for c in np.unique(chosen)}), flush=True)
+    print("class %-4s frames %4d  decode %8.2f ms  %7.2f Gsamples/s  codecs %s" % (
+        klass, nf, dt * 1e3, n / dt / 1e9, {int(c): int(np.sum(chosen == c)) for c in np.unique(chosen)}), flush=True)
     del dp, d_body, d_out
