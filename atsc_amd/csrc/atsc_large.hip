@@ -1357,6 +1357,67 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
 // --------------------------------------------------------------------------------------------
 // k_decompress_large: CompressorFrame::decompress for frames of 4097 .. 131072 samples
 // --------------------------------------------------------------------------------------------
+// Payload reader of the large decoder.  A payload's varint fields are sequential by construction (up to
+// 13100 FFT entries, 131072 Noop values), and a byte at a time out of global memory costs a memory round
+// trip per dependent read.  The first wavefront walks the payload in lock step (every lane computes the
+// same thing) and keeps a 16 KB window of it in LDS, refilled by the 64 lanes together.
+constexpr uint32_t STG_BYTES = 16384;
+struct RdS {
+    const uint8_t *g;  // payload in global memory
+    uint32_t len, pos;
+    bool bad;
+    uint8_t *stg;      // LDS window of STG_BYTES
+    uint32_t w0, w1;   // payload bytes [w0, w1) are staged
+};
+DEVI void rds_fill(RdS &r)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    r.w0 = r.pos;
+    const uint32_t nbytes = min(r.len - r.w0, STG_BYTES);
+    for (uint32_t o = lane * 4; o < nbytes; o += 64 * 4) {  // byte-granular source alignment: 4 bytes per lane
+        uint32_t v = 0;
+        const uint32_t left = min(nbytes - o, 4u);
+        for (uint32_t b = 0; b < left; ++b) v |= (uint32_t)r.g[r.w0 + o + b] << (8 * b);
+        *(uint32_t *)(r.stg + o) = v;
+    }
+    r.w1 = r.w0 + nbytes;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+DEVI uint32_t rds_u8(RdS &r)
+{
+    if (r.pos + 1 > r.len) { r.bad = true; return 0; }
+    if (r.pos >= r.w1) rds_fill(r);
+    return r.stg[r.pos++ - r.w0];
+}
+DEVI uint64_t rds_le(RdS &r, uint32_t nb)
+{
+    if (r.pos + nb > r.len) { r.bad = true; return 0; }
+    if (r.pos + nb > r.w1) rds_fill(r);  // nb <= 8 << window
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)r.stg[r.pos + i - r.w0] << (8 * i);
+    r.pos += nb;
+    return v;
+}
+DEVI uint64_t rds_varint(RdS &r)
+{
+    const uint32_t t = rds_u8(r);
+    if (t < 251) return t;
+    if (t == 251) return rds_le(r, 2);
+    if (t == 252) return rds_le(r, 4);
+    if (t == 253) return rds_le(r, 8);
+    r.bad = true;
+    return 0;
+}
+DEVI double rds_value(RdS &r, uint32_t bd)
+{
+    if (bd == 3) return (double)rds_u8(r);
+    if (bd == 2) return (double)(int16_t)unzig(rds_varint(r));
+    if (bd == 1) return (double)(int32_t)unzig(rds_varint(r));
+    return __longlong_as_double((long long)rds_le(r, 8));
+}
+DEVI float rds_f32(RdS &r) { return __uint_as_float((uint32_t)rds_le(r, 4)); }
+
 // PH 0: the whole decoder.  PH 1 / PH 2: the decoder around the batched inverse transform -- PH 1 parses,
 // decodes every codec but FFT completely and leaves an FFT frame's conjugated packed spectrum in buffer A
 // (DecPending in the workspace); k_large_pre1 / k_large_pre2 <DevDFrame, true> transform all pending frames
@@ -1392,6 +1453,8 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     float2 *Xs = (float2 *)(ws + lay.o_x);
     double *vals = (double *)(ws + lay.o_tab);    // knot values / RLE group values (8n bytes)
     uint64_t *keys = (uint64_t *)(ws + lay.o_rec);  // RLE (start << 32 | group)
+    Sel *ent = (Sel *)(ws + lay.o_sel);           // FFT entries parsed in parallel (<= kcap of them)
+    uint32_t *own = (uint32_t *)(ws + lay.o_aux);  // per position: 1 + index of the last entry that names it
     const float2 *tw = twpool + P.tw_off;
     (void)wsum;
     DecPending *pend = (DecPending *)(ws + lay.o_cnt);
@@ -1427,30 +1490,30 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     }
     __syncthreads();
 
-    if (tid == 0) {
-        Rd r{pay, fr.payload_len, 0, false};
+    if (tid < 64) {  // the first wavefront walks the payload in lock step: every lane writes the same values
+        RdS r{pay, fr.payload_len, 0, false, smem + 256, 0, 0};
         Hdr h;
         h.d0 = h.d1 = 0.0; h.u0 = h.u1 = h.u2 = 0; h.f0 = h.f1 = 0.0f;
         switch (fr.tag) {
         case ATSC_CONSTANT: {
-            (void)rd_u8(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
             if (bd > 3) r.bad = true;
-            else h.d0 = rd_value(r, bd);
+            else h.d0 = rds_value(r, bd);
             break;
         }
         case ATSC_NOOP: {
-            (void)rd_u8(r);
-            const uint64_t cnt = rd_varint(r);
+            (void)rds_u8(r);
+            const uint64_t cnt = rds_varint(r);
             if (cnt != n) r.bad = true;
-            for (uint32_t i = 0; i < n && !r.bad; ++i) out[i] = (double)unzig(rd_varint(r));
+            for (uint32_t i = 0; i < n && !r.bad; ++i) out[i] = (double)unzig(rds_varint(r));
             break;
         }
         case ATSC_IDW:
         case ATSC_POLYNOMIAL: {
-            const uint32_t id = (uint32_t)rd_varint(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
-            const uint64_t cnt = rd_varint(r);
+            const uint32_t id = (uint32_t)rds_varint(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t cnt = rds_varint(r);
             if (id > 1 || bd > 3 || cnt > n) r.bad = true;
             h.f1 = (float)id;  // 0 Polynomial, 1 Idw
             h.u2 = bd;
@@ -1461,44 +1524,102 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
                     r.pos += (uint32_t)cnt * (bd == 0 ? 8u : 1u);
                     if (r.pos > r.len) r.bad = true;
                 } else {
-                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) vals[i] = rd_value(r, bd);
+                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) vals[i] = rds_value(r, bd);
                 }
             }
-            h.d0 = __longlong_as_double((long long)rd_le(r, 8));
-            h.d1 = __longlong_as_double((long long)rd_le(r, 8));
-            h.f0 = (float)rd_u8(r);  // point_step
+            h.d0 = __longlong_as_double((long long)rds_le(r, 8));
+            h.d1 = __longlong_as_double((long long)rds_le(r, 8));
+            h.f0 = (float)rds_u8(r);  // point_step
             break;
         }
         case ATSC_FFT: {
-            (void)rd_u8(r);
-            const uint64_t cnt = rd_varint(r);
+            (void)rds_u8(r);
+            const uint64_t cnt = rds_varint(r);
             if (cnt > L) r.bad = true;
+            if (!r.bad && cnt <= P.kcap) {
+                // An entry is varint(pos: u16) + f32 + f32 = 9 bytes (pos < 251) or 11 (marker 251 + 2).
+                // 64 entries at a time: lane l assumes 11-byte entries before it, corrected by c = the
+                // number of 9-byte entries among them; c is the exclusive prefix sum of the 9-byte flags
+                // read at the assumed starts, iterated to its fixed point (lane 0 is right at once, lane
+                // k after at most k more rounds; short entries are rare, so one or two rounds usually).
+                // The entries go to the workspace; the whole workgroup applies them below.
+                uint32_t done = 0;
+                while (done < cnt && !r.bad) {
+                    const uint32_t grp = min(64u, (uint32_t)cnt - done);
+                    if (r.pos + 11 * 64 > r.w1 && r.w1 < r.len) rds_fill(r);
+                    uint32_t c = 0, st = 0, first = 251, incl = 0;
+                    for (int it = 0; it < 66; ++it) {
+                        st = r.pos + 11 * tid - 2 * c;
+                        first = (tid < grp && st < r.len) ? r.stg[st - r.w0] : 251u;
+                        const uint32_t sf = (tid < grp && first < 251) ? 1u : 0u;
+                        incl = wave_incl_scan_u32(sf);
+                        const uint32_t cn = incl - sf;
+                        const bool moved = cn != c;
+                        c = cn;
+                        if (__ballot(moved) == 0) break;
+                    }
+                    bool lbad = false;
+                    if (tid < grp) {
+                        uint32_t pos = first, o = st + 1;
+                        if (first == 251) {
+                            if (st + 3 > r.len) lbad = true;
+                            else pos = (uint32_t)r.stg[st + 1 - r.w0] | ((uint32_t)r.stg[st + 2 - r.w0] << 8);
+                            o = st + 3;
+                        } else if (first > 251) {
+                            lbad = true;  // a u16 field: 4- and 8-byte varints cannot occur
+                        }
+                        if (!lbad && o + 8 > r.len) lbad = true;
+                        if (!lbad) {
+                            uint32_t wre = 0, wim = 0;
+                            for (uint32_t b = 0; b < 4; ++b) {
+                                wre |= (uint32_t)r.stg[o + b - r.w0] << (8 * b);
+                                wim |= (uint32_t)r.stg[o + 4 + b - r.w0] << (8 * b);
+                            }
+                            float re = __uint_as_float(wre), im = __uint_as_float(wim);
+                            if (pos >= L) {
+                                lbad = true;
+                            } else {
+                                if (pos > L / 2) { pos = L - pos; im = -im; }  // get_mirrored_freqs (fft.rs:401-422)
+                                if (pos == 0 || 2 * pos == L) im = 0.0f;
+                                ent[done + tid].pos = pos;
+                                ent[done + tid].re = re;
+                                ent[done + tid].im = im;
+                            }
+                        }
+                    }
+                    if (__ballot(lbad)) { r.bad = true; break; }
+                    r.pos += 11 * grp - 2 * (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    done += grp;
+                }
+                h.u1 = 1;  // entries wait in the workspace
+            } else
+            // (a foreign stream with more entries than this library's encoder ever stores: one at a time)
             // get_mirrored_freqs (fft.rs:401-422): entries are applied in stream order, later ones
             // overwrite; a position above L/2 is the mirror of L - pos
             for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
-                uint32_t pos = (uint32_t)rd_varint(r) & 0xffffu;
-                float re = rd_f32(r), im = rd_f32(r);
+                uint32_t pos = (uint32_t)rds_varint(r) & 0xffffu;
+                float re = rds_f32(r), im = rds_f32(r);
                 if (pos >= L) { r.bad = true; break; }
                 if (pos > L / 2) { pos = L - pos; im = -im; }
                 Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(re, 0.0f) : make_float2(re, im);
             }
             h.u0 = (uint32_t)cnt;
-            h.f0 = rd_f32(r);
-            h.f1 = rd_f32(r);
+            h.f0 = rds_f32(r);
+            h.f1 = rds_f32(r);
             break;
         }
         case ATSC_RLE: {
-            (void)rd_u8(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
-            const uint64_t groups = rd_varint(r);
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t groups = rds_varint(r);
             if (bd > 3 || groups > n) r.bad = true;
             uint32_t e = 0;
             for (uint32_t gi = 0; gi < groups && !r.bad; ++gi) {
-                vals[gi] = rd_value(r, bd);
-                const uint64_t cnt = rd_varint(r);
+                vals[gi] = rds_value(r, bd);
+                const uint64_t cnt = rds_varint(r);
                 if (cnt > n - e) { r.bad = true; break; }
                 for (uint32_t k = 0; k < cnt && !r.bad; ++k) {
-                    const uint64_t idx = rd_varint(r);
+                    const uint64_t idx = rds_varint(r);
                     if (idx >= n) { r.bad = true; break; }
                     keys[e++] = (idx << 32) | gi;
                 }
@@ -1510,7 +1631,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
         }
         h.bad = r.bad ? 1u : 0u;
         *hdr = h;
-        if (r.bad) atomicExch(status, 1);
+        if (r.bad && tid == 0) atomicExch(status, 1);
     }
     __syncthreads();
     const Hdr h = *hdr;
@@ -1561,6 +1682,68 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             }
             __syncthreads();
         }
+        if (!idw && step > 1) {
+            // Catmull-Rom with the tables of k_compress_large (bit-identical there to the oracle's
+            // polynomial_to_data): tangents once per segment, Hermite basis once per in-segment offset,
+            // exact r / step by the reciprocal with one FMA correction; linear first and last segment.
+            double2 *mm = (double2 *)(ws + lay.o_mm);
+            double4 *hbt = (double4 *)(smem + 256);  // step <= 255 entries of 32 B: the payload window is done with
+            const uint32_t gapL = (n - 1) - (K - 2) * step;
+            const double stepd = (double)step, gapLd = (double)gapL;
+            const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+            for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
+                const uint32_t t0i = sg * step;
+                const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                const uint32_t tmi = (sg - 1) * step;
+                const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                const double t0 = (double)t0i, t1 = (double)t1i;
+                const double v0 = vals[sg], v1 = vals[sg + 1], vm = vals[sg - 1], vp = vals[sg + 2];
+                double2 t;
+                t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                mm[sg] = t;
+            }
+            for (uint32_t r = tid; r < step; r += T) {
+                const double nt = div_small((double)r, stepd, ry);
+                const double t2 = nt * nt;
+                const double t3 = t2 * nt;
+                const double two_t3 = t3 * 2.0;
+                const double two_t2 = t2 * 2.0;
+                const double three_t2 = t2 * 3.0;
+                double4 hh;
+                hh.x = two_t3 - three_t2 + 1.0;
+                hh.y = t3 - two_t2 + nt;
+                hh.z = three_t2 - two_t3;
+                hh.w = t3 - t2;
+                hbt[r] = hh;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += T) {
+                double sv;
+                if (i == n - 1) {
+                    sv = vals[K - 1];
+                } else {
+                    uint32_t sg = __umulhi(i, magic);
+                    if (sg > K - 2) sg = K - 2;
+                    const uint32_t t0i = sg * step;
+                    const bool last = (sg == K - 2);
+                    const double v0 = vals[sg], v1 = vals[sg + 1];
+                    if (sg > 0 && !last) {
+                        const double2 t = mm[sg];
+                        const double4 hh = hbt[i - t0i];
+                        sv = v0 * hh.x + t.x * hh.y + v1 * hh.z + t.y * hh.w;
+                    } else {
+                        const double nt = div_small((double)(i - t0i), last ? gapLd : stepd, last ? ryL : ry);
+                        sv = v0 * (1.0 - nt) + v1 * nt;
+                    }
+                }
+                double o = div1e5(round(sv * 100000.0));
+                if (o < mn) o = mn;
+                else if (o > mx) o = mx;
+                out[i] = o;
+            }
+            return;
+        }
         for (uint32_t j = tid; j < n; j += T) {
             double sv;
             if (idw) {
@@ -1592,6 +1775,20 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
         if (mxf == mnf) {
             for (uint32_t j = tid; j < n; j += T) out[j] = (double)mxf;
             return;
+        }
+        if (h.u1) {
+            // entries are applied in stream order, later ones overwrite (fft.rs:401-422): the last entry
+            // naming a position owns it
+            const uint32_t cnt = h.u0, nbin = L / 2 + 1;
+            for (uint32_t k = tid; k < nbin; k += T) own[k] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += T) atomicMax(&own[ent[i].pos], i + 1);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += T) {
+                const Sel e = ent[i];
+                if (own[e.pos] == i + 1) Xs[e.pos] = make_float2(e.re, e.im);
+            }
+            __syncthreads();
         }
         float2 *F;
         if (P.half) {
@@ -1678,7 +1875,7 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
         if (split) {
             // parse + every codec but the FFT transform; the transform of all pending frames over the whole
             // GPU; scale / round / clamp
-            hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
+            hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256 + STG_BYTES, s, frames, ids + b0, plans, twpool,
                                body, out, status, ws, ws_stride, tiled);
             hipLaunchKernelGGL((k_large_pre1<DevDFrame, true>), dim3(pre->tiles1, nb), dim3(PT), lds1, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
