@@ -31,7 +31,7 @@ uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, hipStream_t s, const LargePre *pre = nullptr);
+                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre = nullptr);
 hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
                                 uint32_t *hist_cursor, const uint32_t *class_first,
                                 const uint32_t *class_count, int n_classes, hipStream_t s);
@@ -259,6 +259,9 @@ static bool choose_large_tiled(uint32_t n_large_frames)
     if (const char *e = getenv("ATSC_LARGE_FFT")) tiled = strcmp(e, "tiled") == 0;
     return tiled;
 }
+// Inverse transforms of the large tier run from the sparse list of admitted bins (sparse_inverse,
+// atsc_large.hip); ATSC_LARGE_DENSE=1 keeps the dense transforms through the workspace (A/B runs).
+static bool large_sparse() { return getenv("ATSC_LARGE_DENSE") == nullptr; }
 // Grid extents of the batched pre-pass (forward transform, untangle, norms of every large frame over
 // the whole GPU before the per-frame kernel); all zero when a large frame length has no M1 x M2 split.
 static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
@@ -355,6 +358,12 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         uint32_t d = (uint32_t)std::sqrt((double)p.M);
         while (d > 1 && p.M % d != 0) --d;
         if (d > 1 && p.M / d <= 480) { p.f4_m1 = d; p.f4_m2 = p.M / d; }
+    }
+    p.sp_mf = p.sp_md = 0;
+    if (!p.direct && p.M >= 1024) {
+        uint32_t d = std::min(p.M, 992u);
+        while (d > 1 && p.M % d != 0) --d;
+        if (d >= 64 && p.M / d <= 256) { p.sp_mf = d; p.sp_md = p.M / d; }
     }
     p.p2bins = pow2_ge(p.bins);
     p.p2n = pow2_ge(n);
@@ -911,6 +920,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.trial_res = nullptr;
     prm.cost = nullptr;
     prm.large_tiled = 0;
+    prm.sparse_inv = large_sparse() ? 1u : 0u;
     prm.prefft = 0;
     if (compressor == ATSC_AUTO && sample_level > 0) {
         if (!plan->trials[sample_level]) {
@@ -1298,7 +1308,8 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
         if (c == CLASS_LARGE)
             e = launch_decompress_large(dp->class_count[c], dp->d_frames, dp->d_ids + dp->class_first[c],
                                         dp->tabs.d_plans, dp->tabs.d_tw, d_body, d_out, dp->d_status,
-                                        dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0, s,
+                                        dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0,
+                                        large_sparse() ? 1 : 0, s,
                                         dp->large_pre.tiles1 ? &dp->large_pre : nullptr);
         else
             e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,

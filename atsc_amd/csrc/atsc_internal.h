@@ -27,6 +27,9 @@ struct DevPlan {
     uint32_t magicL;   // floor(2^32 / L) + 1 (L >= 2): x mod L without a divide
     uint32_t f4_m1, f4_m2;  // M = f4_m1 * f4_m2, f4_m1 <= f4_m2 as close as the factors allow (0: no usable
                             // split): the large tier's LDS-tiled two-pass transform
+    uint32_t sp_mf, sp_md;  // M = sp_mf * sp_md, sp_mf the largest divisor <= 992 (0: none): the large
+                            // tier's inverse transform from the sparse list of admitted bins -- a direct
+                            // sum over sp_md, then LDS transforms of length sp_mf (atsc_large.hip)
     uint32_t lds_bytes;
     // LDS carve offsets (bytes, 16-aligned).  AB = two FFT work buffers of ab_half bytes each,
     // later reused for spline tables, RLE run records and the RLE hash table.
@@ -114,6 +117,7 @@ struct KParams {
     const DevResult *trial_res;  // results of the trial launch (indexed like the frames), or null
     uint32_t *cost;              // per frame: shader clocks / 64 this launch took (scheduling hint), or null
     uint32_t large_tiled;        // large tier: in-kernel transforms take the LDS-tiled two-pass form
+    uint32_t sparse_inv;         // large tier: per-trip inverse transform from the sparse bin list
     uint32_t prefft;             // large tier: forward transform, untangle and norms were done by the
                                  // batched pre-pass kernels (spectrum, norm bits and non-zero count are
                                  // in the frame's workspace slot)

@@ -184,7 +184,7 @@ constexpr uint32_t F4_TILE = FB * (F4_MAX + 1);  // float2 per tile buffer
 
 // Stockham over `nseq` sequences of length N held in LDS, element (i, c) at i * si + c * sq.
 // CF: consecutive work items walk the sequences first (si = FB, sq = 1), else the butterflies first.
-template <bool CF>
+template <bool CF, uint32_t FBX = FB>
 DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_t nseq, uint32_t si, uint32_t sq,
                      uint32_t nt = LT)
 {
@@ -194,10 +194,10 @@ DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_
         const uint32_t m = ncur / r, nbf = N / r, sm = st * m;
         const uint32_t mg_st = st > 1 ? (uint32_t)(0x100000000ull / st) + 1u : 0u;
         const uint32_t mg_nb = nbf > 1 ? (uint32_t)(0x100000000ull / nbf) + 1u : 0u;
-        const uint32_t total = CF ? nbf * FB : nbf * nseq;
+        const uint32_t total = CF ? nbf * FBX : nbf * nseq;
         for (uint32_t w = threadIdx.x; w < total; w += nt) {
             uint32_t b, c;
-            if (CF) { c = w & (FB - 1); b = w >> 4; if (c >= nseq) continue; }
+            if (CF) { c = w & (FBX - 1); b = w / FBX; if (c >= nseq) continue; }
             else { c = nbf > 1 ? __umulhi(w, mg_nb) : w; b = w - c * nbf; }
             const uint32_t p = st > 1 ? __umulhi(b, mg_st) : b;
             const uint32_t q = b - p * st;
@@ -324,6 +324,166 @@ uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap) { return large_ws
 DEVI uint32_t lscan(uint32_t *arr, uint32_t count, uint32_t *wsum)
 {
     return block_excl_scan<LW>(arr, count, wsum);
+}
+
+// --------------------------------------------------------------------------------------------
+// Inverse transform straight from the sparse list of admitted bins.
+//
+// A ladder trip (and the decoder) transforms a spectrum that holds K non-zero bins out of L/2 + 1
+// (K starts at n/100).  Run as a dense transform that costs two passes over the whole packed spectrum
+// through the workspace plus the pass that builds it; here nothing dense ever leaves the CU.  With
+// M = Mf * Md (DevPlan::sp_mf, sp_md), input index k = ka + Mf kb and output index j = Md ja + jb:
+//
+//   F[Md ja + jb] = sum_ka W_Mf^{ja ka} * W_M^{jb ka} * G[ka][jb],   G[ka][jb] = sum_kb Z[ka + Mf kb] W_Md^{jb kb}
+//
+// G is a direct sum over the list (each admitted bin gives at most two points of the packed spectrum
+// Z, so K * 2 * Md multiply-adds per trip); what remains is a batch of length-Mf transforms in LDS,
+// SPB output columns jb at a time, whose results feed the evaluation (error sum or decoded samples)
+// directly: 2 * SPB consecutive samples per run.  The list is bucketed by ka once per trip (LDS
+// counters, scan, scatter, then each bucket put in ascending (kb, kind) order by one thread so that the
+// f32 sums do not depend on the order the atomics happened to serve).
+// --------------------------------------------------------------------------------------------
+constexpr uint32_t SPB = 8;          // output columns per LDS tile
+constexpr uint32_t SP_MF_MAX = 992;  // longest LDS sub-transform (host: DevPlan::sp_mf)
+constexpr uint32_t SP_MD_MAX = 256;
+constexpr uint32_t SP_LDS_BYTES = (2 * SPB * SP_MF_MAX + SP_MF_MAX + SP_MD_MAX) * 8 + (2 * SP_MF_MAX + 8) * 4;
+
+struct SpEnt {
+    uint32_t key;  // kb << 1 | kind
+    float re, im;
+};
+
+// entry(i, p, x): bin position p (<= L/2) and value x of list entry i, false if the entry is void;
+// ev(j, re): sample j of the padded signal before the division by L.  zl: 2 K entries of scratch.
+template <class EntryFn, class EvalFn>
+DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl, const float2 *tw,
+                         unsigned char *lds, uint32_t *wsum, EvalFn ev, uint32_t dbg = 0)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Mf = P.sp_mf, Md = P.sp_md, M = P.M, L = P.L, sc = P.sc;
+    const bool half = P.half != 0;
+    float2 *T = (float2 *)lds, *U = T + SPB * Mf, *wf = U + SPB * Mf, *wd = wf + Mf;
+    uint32_t *beg = (uint32_t *)(wd + Md), *end = beg + Mf + 4;
+    const uint32_t mg_mf = (uint32_t)(0x100000000ull / Mf) + 1u;
+    const uint32_t mg_md = Md >= 2 ? (uint32_t)(0x100000000ull / Md) + 1u : 0u;
+
+    for (uint32_t e = tid; e < Mf; e += LT) {
+        wf[e] = tw[e * (L / Mf)];
+        beg[e] = 0;
+    }
+    for (uint32_t e = tid; e < Md; e += LT) wd[e] = tw[e * (L / Md)];
+    __syncthreads();
+
+    // points of the packed (even L) or full (odd L) conjugated spectrum that entry i feeds
+    auto points = [&](uint32_t i, uint32_t (&kk)[2], float2 (&vv)[2]) -> uint32_t {
+        uint32_t p;
+        float2 x;
+        if (!entry(i, p, x)) return 0;
+        uint32_t c = 0;
+        if (half) {
+            // k_compress_large's dense form, one source bin at a time:
+            //   Z[k] = conj(E + i O),  E = (X[k] + conj X[M-k]) / 2,  O = (X[k] - conj X[M-k]) / 2 * w^k
+            if (p < M) {
+                const float2 h = make_float2(0.5f * x.x, 0.5f * x.y);
+                const float2 o = cmulp(h, tw[p]);
+                kk[c] = p;
+                vv[c] = make_float2(h.x - o.y, -(h.y + o.x));
+                ++c;
+            }
+            if (p >= 1) {
+                const float2 e = make_float2(0.5f * x.x, -0.5f * x.y);
+                const float2 d = make_float2(-0.5f * x.x, 0.5f * x.y);
+                const float2 o = cmulp(d, tw[M - p]);
+                kk[c] = (M - p) | 0x80000000u;
+                vv[c] = make_float2(e.x - o.y, -(e.y + o.x));
+                ++c;
+            }
+        } else {
+            kk[c] = p;
+            vv[c] = make_float2(x.x, -x.y);
+            ++c;
+            if (p >= 1 && 2 * p != L) {
+                kk[c] = (L - p) | 0x80000000u;
+                vv[c] = make_float2(x.x, x.y);
+                ++c;
+            }
+        }
+        return c;
+    };
+    for (uint32_t i = tid; i < K; i += LT) {
+        uint32_t kk[2];
+        float2 vv[2];
+        const uint32_t c = points(i, kk, vv);
+        for (uint32_t q = 0; q < c; ++q) {
+            const uint32_t k = kk[q] & 0x7fffffffu;
+            atomicAdd(&beg[k - __umulhi(k, mg_mf) * Mf], 1u);
+        }
+    }
+    __syncthreads();
+    (void)block_excl_scan<LW>(beg, Mf, wsum);
+    for (uint32_t e = tid; e < Mf; e += LT) end[e] = beg[e];
+    __syncthreads();
+    for (uint32_t i = tid; i < K; i += LT) {
+        uint32_t kk[2];
+        float2 vv[2];
+        const uint32_t c = points(i, kk, vv);
+        for (uint32_t q = 0; q < c; ++q) {
+            const uint32_t k = kk[q] & 0x7fffffffu;
+            const uint32_t kb = __umulhi(k, mg_mf), ka = k - kb * Mf;
+            const uint32_t slot = atomicAdd(&end[ka], 1u);
+            SpEnt z;
+            z.key = (kb << 1) | (kk[q] >> 31);
+            z.re = vv[q].x;
+            z.im = vv[q].y;
+            zl[slot] = z;
+        }
+    }
+    __syncthreads();
+    for (uint32_t ka = tid; ka < Mf; ka += LT) {
+        const uint32_t b = beg[ka], e = end[ka];
+        for (uint32_t a = b + 1; a < e; ++a) {
+            const SpEnt t = zl[a];
+            uint32_t j = a;
+            while (j > b && zl[j - 1].key > t.key) { zl[j] = zl[j - 1]; --j; }
+            zl[j] = t;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t jb0 = 0; jb0 < Md; jb0 += SPB) {
+        const uint32_t nseq = min(SPB, Md - jb0);
+        for (uint32_t w = tid; w < Mf * SPB; w += LT) {
+            const uint32_t c = w & (SPB - 1), ka = w / SPB;
+            if (c >= nseq) continue;
+            const uint32_t jb = jb0 + c;
+            float2 acc = make_float2(0.0f, 0.0f);
+            const uint32_t e1 = (dbg & 1) ? 0u : end[ka];
+            for (uint32_t e = beg[ka]; e < e1; ++e) {
+                const SpEnt z = zl[e];
+                const uint32_t x = jb * (z.key >> 1);
+                const float2 t = cmulc(make_float2(z.re, z.im), wd[Md >= 2 ? mod_magic(x, Md, mg_md) : 0u]);
+                acc.x += t.x;
+                acc.y += t.y;
+            }
+            T[ka * SPB + c] = cmulc(acc, tw[jb * ka * sc]);
+        }
+        __syncthreads();
+        const float2 *R = (dbg & 2) ? T : lds_fft<true, SPB>(T, U, wf, Mf, nseq, SPB, 1);
+        if (dbg & 4) continue;
+        for (uint32_t w = tid; w < Mf * SPB; w += LT) {
+            const uint32_t c = w & (SPB - 1), ja = w / SPB;
+            if (c >= nseq) continue;
+            const float2 f = R[ja * SPB + c];
+            const uint32_t j = Md * ja + jb0 + c;
+            if (half) {  // idft_L = 2 * idft_M: even sample -> re, odd sample -> -im
+                ev(2 * j, 2.0f * f.x);
+                ev(2 * j + 1, -2.0f * f.y);
+            } else {
+                ev(j, f.x);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // sort of u64 run records rec = (start << 32 | end) by (bits of xs[end], start)
@@ -484,7 +644,8 @@ __global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ s
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
                                                     const float2 *__restrict__ twpool,
-                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+                                                    int sparse_inv)
 {
     const DevPlan *P;
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
@@ -513,7 +674,7 @@ __global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ s
         }
         nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
         zeros = (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
-        Xs[k] = make_float2(0.0f, 0.0f);
+        if (!(sparse_inv && P->sp_mf)) Xs[k] = make_float2(0.0f, 0.0f);  // the dense ladder's admitted spectrum
     }
     // fft.rs:249-252 needs the number of non-zero bins; zero bins are the rare ones, so they are what
     // gets counted (a same-address atomic per wavefront serialised ~1100 deep per frame otherwise)
@@ -585,6 +746,14 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     // ---- stats --------------------------------------------------------------------------------
     double smin, smax;
     uint32_t bitdepth;
+    // the codec a sample-level trial picked replaces Auto further down; known here already, it tells
+    // whether the one pass over the samples should count the RLE runs as well (rle.rs:142-189)
+    const bool rle_wanted = [&] {
+        int m = mode;
+        if (m == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n) m = (int)prm.trial_res[fid].chosen;
+        return m == ATSC_AUTO || m == ATSC_RLE;
+    }();
+    uint32_t st_runs = 0, st_ibytes = 0;
     {
         const double x0 = xs[0];
         double mn = x0, mx = x0;
@@ -594,20 +763,29 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             fr_any |= frac_nonzero(v) ? 1u : 0u;
             if (v > mx) mx = v;
             if (v < mn) mn = v;
+            if (rle_wanted && (j == 0 || v != xs[j - 1])) { ++st_runs; st_ibytes += vlen(j); }
         }
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
+        // The extremes are reported with the bits of their first occurrence.  Doubles that compare
+        // equal have equal bits unless they are zeros of either sign, so only a zero extreme needs
+        // the second pass.
         uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
-        for (uint32_t j = tid; j < n; j += T) {
-            const double v = xs[j];
-            if (v == mn) mni = min(mni, j);
-            if (v == mx) mxi = min(mxi, j);
+        if (mn == 0.0 || mx == 0.0) {
+            for (uint32_t j = tid; j < n; j += T) {
+                const double v = xs[j];
+                if (v == mn) mni = min(mni, j);
+                if (v == mx) mxi = min(mxi, j);
+            }
+            mni = block_min_u32<W>(mni, red, parity);
+            mxi = block_min_u32<W>(mxi, red, parity);
+            smin = (mni < n) ? xs[mni] : x0;
+            smax = (mxi < n) ? xs[mxi] : x0;
+        } else {
+            smin = (mn == mn) ? mn : x0;
+            smax = (mx == mx) ? mx : x0;
         }
-        mni = block_min_u32<W>(mni, red, parity);
-        mxi = block_min_u32<W>(mxi, red, parity);
         fr_any = block_or_u32<W>(fr_any, red, parity);
-        smin = (mni < n) ? xs[mni] : x0;
-        smax = (mxi < n) ? xs[mxi] : x0;
         int64_t maxi, mini;
         bool fz;
         split_n(smax, maxi, fz);
@@ -735,11 +913,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         rle_sorted = true;
     };
     if (run_rle) {
-        uint32_t rcnt = 0, ibs = 0;
-        for (uint32_t j = tid; j < n; j += T)
-            if (j == 0 || xs[j] != xs[j - 1]) { ++rcnt; ibs += vlen(j); }
-        rle_R = block_sum_u32<W>(rcnt, red, parity);
-        rle_ib = block_sum_u32<W>(ibs, red, parity);
+        rle_R = block_sum_u32<W>(st_runs, red, parity);  // counted with the statistics
+        rle_ib = block_sum_u32<W>(st_ibytes, red, parity);
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
         rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * (minval + 1);
         if (mode == ATSC_RLE || rle_R <= 1024) {
@@ -805,7 +980,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     const float2 z = spec[k];
                     nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
                     nz += (z.x != 0.0f || z.y != 0.0f) ? 1u : 0u;
-                    Xs[k] = make_float2(0.0f, 0.0f);
+                    if (!(prm.sparse_inv && P.sp_mf)) Xs[k] = make_float2(0.0f, 0.0f);
                 }
                 __syncthreads();
                 Z = block_sum_u32<W>(nz, red, parity);
@@ -822,6 +997,65 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 nkeys = bins;
                 __syncthreads();
             } else {
+                // One histogram pass over the top 11 bits of the norm patterns (exponent + 3 mantissa
+                // bits: the counters of one exponent are spread over 8 addresses) finds the digit d* in
+                // which the kcap-th largest norm falls; one more pass collects the bins above d* (all
+                // admitted) and the bins in d* (candidates) into LDS.  Candidates sort on their own:
+                // every key above d* precedes every candidate, so the two sorted lists concatenate.
+                // Lists that do not fit take the byte-wise radix select below.
+                uint32_t *h2 = (uint32_t *)keys;  // 2048 counters, index 2047 - digit
+                for (uint32_t i = tid; i < 2048; i += T) h2[i] = 0;
+                if (tid == 0) { bc[2] = 0; bc[3] = 0; bc[4] = 0xFFFFFFFFu; }
+                __syncthreads();
+                for (uint32_t k = tid; k < bins; k += T) atomicAdd(&h2[2047u - (nbits[k] >> 20)], 1u);
+                __syncthreads();
+                {
+                    const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
+                    __syncthreads();
+                    (void)block_excl_scan<W>(h2, 2048, wsum);  // h2[i] = bins with a digit above 2047 - i
+                    const uint32_t a0 = h2[2 * tid], a1 = h2[2 * tid + 1];
+                    if (a0 < kcap && a0 + c0 >= kcap) { bc[4] = 2 * tid; bc[5] = a0; bc[6] = c0; }
+                    if (a1 < kcap && a1 + c1 >= kcap) { bc[4] = 2 * tid + 1; bc[5] = a1; bc[6] = c1; }
+                    __syncthreads();
+                }
+                const uint32_t dstar = 2047u - bc[4], n_above = bc[5], n_cand = bc[6];
+                constexpr uint32_t CAND0 = LKEYS_MAX / 2;
+                __syncthreads();
+                if (bc[4] != 0xFFFFFFFFu && n_above <= CAND0 && n_cand <= LKEYS_MAX - CAND0) {
+                    const uint32_t lane = tid & 63u;
+                    const uint64_t lt = (1ull << lane) - 1ull;
+                    for (uint32_t k0 = 0; k0 < bins; k0 += T) {
+                        const uint32_t k = k0 + tid;
+                        const uint32_t v = k < bins ? nbits[k] : 0u;
+                        const uint32_t d = v >> 20;
+                        const bool ab = k < bins && d > dstar, cd = k < bins && d == dstar;
+                        const uint64_t key = ((uint64_t)(~v) << 32) | (uint64_t)k;
+                        const uint64_t ma = __ballot(ab), mc = __ballot(cd);
+                        if (ma) {
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&bc[2], (uint32_t)__popcll(ma));
+                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                            if (ab) keys[base + (uint32_t)__popcll(ma & lt)] = key;
+                        }
+                        if (mc) {
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&bc[3], (uint32_t)__popcll(mc));
+                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                            if (cd) keys[CAND0 + base + (uint32_t)__popcll(mc & lt)] = key;
+                        }
+                    }
+                    __syncthreads();
+                    uint32_t pa = 1, pc = 1;
+                    while (pa < n_above) pa <<= 1;
+                    while (pc < n_cand) pc <<= 1;
+                    block_sort<W, true>(keys, nullptr, n_above, pa);
+                    block_sort<W, true>(keys + CAND0, nullptr, n_cand, pc);
+                    const uint32_t take = kcap - n_above;  // 1 .. n_cand
+                    for (uint32_t i = tid; i < n_above; i += T) spos[i] = (uint32_t)(keys[i] & 0xffffffffu);
+                    for (uint32_t i = tid; i < take; i += T) spos[n_above + i] = (uint32_t)(keys[CAND0 + i] & 0xffffffffu);
+                    __syncthreads();
+                    return kcap;
+                }
                 // radix select of the kcap-th largest norm-bit pattern, 8 bits per pass
                 uint32_t prefix = 0, remaining = kcap;
                 for (int shift = 24; shift >= 0; shift -= 8) {
@@ -901,6 +1135,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
 
             // ---- ladder ----
             const bool wraps = bins > 65536;
+            const bool sparse = prm.sparse_inv != 0 && P.sp_mf != 0;
             uint32_t *own = aux;
             if (wraps) {
                 for (uint32_t i = tid; i < 65536; i += T) own[i] = 0;
@@ -927,10 +1162,10 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     const float2 z = spec[pos];
                     sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
                     if (wraps) atomicMax(&own[pos & 0xffffu], i + 1);
-                    else Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(z.x, 0.0f) : z;
+                    else if (!sparse) Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(z.x, 0.0f) : z;
                 }
                 __syncthreads();
-                if (wraps) {
+                if (wraps && !sparse) {
                     for (uint32_t i = used + tid; i < K; i += T) {
                         const uint32_t p16 = sel[i].pos & 0xffffu;
                         if (own[p16] == i + 1)
@@ -941,6 +1176,32 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 }
                 used = K;
                 if (!prm.bounded) { cur = 0.0; break; }
+                double s = 0.0;
+                if (sparse) {
+                    // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
+                    sparse_inverse(
+                        P, K,
+                        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+                            const Sel e = sel[i];
+                            p = e.pos;
+                            if (wraps) {
+                                p &= 0xffffu;
+                                if (own[p] != i + 1) return false;
+                            }
+                            x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
+                            return true;
+                        },
+                        (SpEnt *)work, tw, (unsigned char *)keys, wsum,
+                        [&](uint32_t j, float re) {
+                            const double v = (double)(re / Lf);
+                            double o = div1e5(round(v * 100000.0));
+                            if (o > mxd) o = mxd;
+                            if (o < mnd) o = mnd;
+                            const double g = gpad(j);
+                            s += fabs(o - g) * recip_abs(g);  // the product form, as in k_compress
+                        },
+                        prm.debug_stop >= 16 ? (uint32_t)prm.debug_stop - 16u : 0u);
+                } else {
                 float2 *F;
                 if (P.half) {
                     // Hermitian spectrum -> packed complex spectrum of (even + i odd) samples, conjugated
@@ -968,7 +1229,6 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     F = fft_large(P, work, Cb, tw, fft_lds, prm.large_tiled != 0);
                 }
                 // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
-                double s = 0.0;
                 for (uint32_t j = tid; j < L; j += T) {
                     float re;
                     if (P.half) {
@@ -983,6 +1243,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     if (o < mnd) o = mnd;
                     const double g = gpad(j);
                     s += fabs((o - g) / g);
+                }
                 }
                 s = block_sum_f64<W>(s, red, parity);
                 cur = s / Ld;
@@ -1004,7 +1265,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         dg.fft_err = fft_err;
     }
 
-    if (prm.debug_stop == 6) return;
+    if (prm.debug_stop == 6 || prm.debug_stop >= 16) return;
     // =========================================================================================
     // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
     // interpolation (polynomial.rs:375-393)
@@ -1319,7 +1580,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
                                  const LargePre *pre)
 {
-    const uint32_t lds = 384 + 1024 + 64 + 8 * LKEYS_MAX;
+    const uint32_t lds = 384 + 1024 + 64 + max(8 * LKEYS_MAX, SP_LDS_BYTES);
     hipError_t e = hipFuncSetAttribute((const void *)k_compress_large,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1343,7 +1604,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             hipLaunchKernelGGL((k_large_pre2<DevFrame, false>), dim3(pre->tiles2, nb), dim3(PT), lds2, s, samples, frames,
                                ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL(k_large_pre3, dim3(pre->chunks, nb), dim3(PT3), 0, s, samples, frames, ids + b0,
-                               plans, twpool, ws, ws_stride);
+                               plans, twpool, ws, ws_stride, (int)kp.sparse_inv);
         }
         hipLaunchKernelGGL(k_compress_large, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
                            twpool, kp, slots, res, diag, ws, ws_stride);
@@ -1427,7 +1688,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
     const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
-    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled)
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse)
 {
     constexpr int T = LT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1485,7 +1746,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
 
     // fixed-width point arrays (U8 / F64) are read in parallel after the header; the spectrum must be
     // empty before lane 0 starts filling it
-    if (fr.tag == ATSC_FFT) {
+    if (fr.tag == ATSC_FFT && !(PH == 0 && sparse && P.sp_mf)) {
         for (uint32_t k = tid; k <= L / 2; k += T) Xs[k] = make_float2(0.0f, 0.0f);
     }
     __syncthreads();
@@ -1596,12 +1857,16 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             // (a foreign stream with more entries than this library's encoder ever stores: one at a time)
             // get_mirrored_freqs (fft.rs:401-422): entries are applied in stream order, later ones
             // overwrite; a position above L/2 is the mirror of L - pos
+            {
+            if (PH == 0 && sparse && P.sp_mf)  // nobody cleared the dense spectrum for this frame yet
+                for (uint32_t k = tid; k <= L / 2; k += 64) Xs[k] = make_float2(0.0f, 0.0f);
             for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
                 uint32_t pos = (uint32_t)rds_varint(r) & 0xffffu;
                 float re = rds_f32(r), im = rds_f32(r);
                 if (pos >= L) { r.bad = true; break; }
                 if (pos > L / 2) { pos = L - pos; im = -im; }
                 Xs[pos] = (pos == 0 || 2 * pos == L) ? make_float2(re, 0.0f) : make_float2(re, im);
+            }
             }
             h.u0 = (uint32_t)cnt;
             h.f0 = rds_f32(r);
@@ -1784,6 +2049,30 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             __syncthreads();
             for (uint32_t i = tid; i < cnt; i += T) atomicMax(&own[ent[i].pos], i + 1);
             __syncthreads();
+            if (PH == 0 && sparse && P.sp_mf) {
+                const double mxd = (double)mxf, mnd = (double)mnf;
+                const float Lf = (float)L;
+                sparse_inverse(
+                    P, cnt,
+                    [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+                        const Sel e = ent[i];
+                        p = e.pos;
+                        x = make_float2(e.re, e.im);
+                        return own[p] == i + 1;
+                    },
+                    (SpEnt *)Cb, tw, smem + 256, wsum,
+                    [&](uint32_t j, float re) {
+                        const uint32_t i = j - pre;
+                        if (i < n) {
+                            const float v = re / Lf;
+                            double o = round((double)v * 100000.0) / 100000.0;
+                            if (o > mxd) o = mxd;
+                            if (o < mnd) o = mnd;
+                            out[i] = o;
+                        }
+                    });
+                return;
+            }
             for (uint32_t i = tid; i < cnt; i += T) {
                 const Sel e = ent[i];
                 if (own[e.pos] == i + 1) Xs[e.pos] = make_float2(e.re, e.im);
@@ -1852,11 +2141,13 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
 hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, hipStream_t s, const LargePre *pre)
+                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre)
 {
     // 256 B of header scratch + the tile buffers of the LDS-tiled inverse transform
-    const uint32_t lds = 256 + (2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2);
-    const bool split = pre && pre->tiles1;
+    const uint32_t lds = 256 + max((2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2), SP_LDS_BYTES);
+    // the batched inverse transform serves the dense form only: from the sparse bin list a frame's
+    // decoder needs no pass over the workspace at all
+    const bool split = pre && pre->tiles1 && !sparse;
     hipError_t e;
     uint32_t lds1 = 0, lds2 = 0;
     if (split) {
@@ -1876,16 +2167,16 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             // parse + every codec but the FFT transform; the transform of all pending frames over the whole
             // GPU; scale / round / clamp
             hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256 + STG_BYTES, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled);
+                               body, out, status, ws, ws_stride, tiled, sparse);
             hipLaunchKernelGGL((k_large_pre1<DevDFrame, true>), dim3(pre->tiles1, nb), dim3(PT), lds1, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL((k_large_pre2<DevDFrame, true>), dim3(pre->tiles2, nb), dim3(PT), lds2, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL(k_decompress_large<2>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled);
+                               body, out, status, ws, ws_stride, tiled, sparse);
         } else {
             hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled);
+                               body, out, status, ws, ws_stride, tiled, sparse);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
