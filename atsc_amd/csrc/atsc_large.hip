@@ -585,20 +585,44 @@ __global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ sa
         i = i < 0 ? 0 : (i >= (int32_t)f.n ? (int32_t)f.n - 1 : i);
         return (float)f.xs[i];
     };
-    for (uint32_t w = threadIdx.x; w < f.M1 * FB; w += PT) {
-        const uint32_t c = w & (FB - 1), n1 = w >> 4;
-        if (c < nseq) {
-            const uint32_t i = f.M2 * n1 + c0 + c;
-            T[n1 * FB + c] = FROM_WS ? Xin[i] : f.half ? make_float2(g(2 * i), g(2 * i + 1)) : make_float2(g(i), 0.0f);
+    // F4_MAX * FB / PT <= 8 points per thread: every global load of a thread is issued before the
+    // first value is used (a tile is a latency-bound gather otherwise)
+    constexpr uint32_t PU = (F4_MAX * FB + PT - 1) / PT;
+    {
+        float2 v[PU];
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            const uint32_t c = w & (FB - 1), n1 = w >> 4;
+            v[u] = make_float2(0.0f, 0.0f);
+            if (w < f.M1 * FB && c < nseq) {
+                const uint32_t i = f.M2 * n1 + c0 + c;
+                v[u] = FROM_WS ? Xin[i] : f.half ? make_float2(g(2 * i), g(2 * i + 1)) : make_float2(g(i), 0.0f);
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            const uint32_t c = w & (FB - 1), n1 = w >> 4;
+            if (w < f.M1 * FB && c < nseq) T[n1 * FB + c] = v[u];
         }
     }
     __syncthreads();
     const float2 *R = lds_fft<true>(T, U, w1, f.M1, nseq, FB, 1, PT);
-    for (uint32_t w = threadIdx.x; w < f.M1 * FB; w += PT) {
-        const uint32_t c = w & (FB - 1), k1 = w >> 4;
-        if (c < nseq) {
-            const uint32_t n2 = c0 + c;
-            Y[k1 * f.M2 + n2] = cmulc(R[k1 * FB + c], tw[n2 * k1 * f.sc]);
+    {
+        float2 t[PU];
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            const uint32_t c = w & (FB - 1), k1 = w >> 4;
+            t[u] = make_float2(1.0f, 0.0f);
+            if (w < f.M1 * FB && c < nseq) t[u] = tw[(c0 + c) * k1 * f.sc];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            const uint32_t c = w & (FB - 1), k1 = w >> 4;
+            if (w < f.M1 * FB && c < nseq) Y[k1 * f.M2 + c0 + c] = cmulc(R[k1 * FB + c], t[u]);
         }
     }
 }
@@ -626,9 +650,23 @@ __global__ __launch_bounds__(PT) void k_large_pre2(const double *__restrict__ sa
     for (uint32_t e = threadIdx.x; e < f.M2; e += PT) w2[e] = tw[e * (f.M1 * f.sc)];
     const uint32_t nseq = min(FB, f.M1 - r0);
     const uint32_t mg_m2 = (uint32_t)(0x100000000ull / f.M2) + 1u;
-    for (uint32_t w = threadIdx.x; w < nseq * f.M2; w += PT) {
-        const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * f.M2;
-        T[r * ld + n2] = Y[(r0 + r) * f.M2 + n2];
+    {
+        constexpr uint32_t PU = (F4_MAX * FB + PT - 1) / PT;
+        float2 v[PU];
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            v[u] = make_float2(0.0f, 0.0f);
+            if (w < nseq * f.M2) v[u] = Y[r0 * f.M2 + w];  // FB rows are one contiguous run
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            if (w < nseq * f.M2) {
+                const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * f.M2;
+                T[r * ld + n2] = v[u];
+            }
+        }
     }
     __syncthreads();
     const float2 *R = lds_fft<false>(T, U, w2, f.M2, nseq, 1, ld, PT);
@@ -758,13 +796,41 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         const double x0 = xs[0];
         double mn = x0, mx = x0;
         uint32_t fr_any = 0;
-        for (uint32_t j = tid; j < n; j += T) {
-            const double v = xs[j];
+        auto visit = [&](uint32_t j, double v, double prev) {
             fr_any |= frac_nonzero(v) ? 1u : 0u;
             if (v > mx) mx = v;
             if (v < mn) mn = v;
-            if (rle_wanted && (j == 0 || v != xs[j - 1])) { ++st_runs; st_ibytes += vlen(j); }
+            if (rle_wanted && (j == 0 || v != prev)) { ++st_runs; st_ibytes += vlen(j); }
+        };
+        // pairs of samples, four pairs of a thread in flight (a frame that does not start on a 16-byte
+        // boundary takes the scalar loop)
+        uint32_t j0 = 0;
+        if (((uintptr_t)xs & 15u) == 0) {
+            const double2 *x2 = (const double2 *)xs;
+            const uint32_t np = n >> 1;
+            for (uint32_t q0 = 0; q0 < np; q0 += 4 * T) {
+                double2 v[4];
+                double pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t q = q0 + u * T + tid;
+                    if (q < np) {
+                        v[u] = x2[q];
+                        pv[u] = q ? xs[2 * q - 1] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t q = q0 + u * T + tid;
+                    if (q < np) {
+                        visit(2 * q, v[u].x, pv[u]);
+                        visit(2 * q + 1, v[u].y, v[u].x);
+                    }
+                }
+            }
+            j0 = 2 * np;
         }
+        for (uint32_t j = j0 + tid; j < n; j += T) visit(j, xs[j], j ? xs[j - 1] : 0.0);
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
         // The extremes are reported with the bits of their first occurrence.  Doubles that compare
