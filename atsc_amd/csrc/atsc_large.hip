@@ -1745,6 +1745,47 @@ DEVI double rds_value(RdS &r, uint32_t bd)
 }
 DEVI float rds_f32(RdS &r) { return __uint_as_float((uint32_t)rds_le(r, 4)); }
 
+// `cnt` consecutive varints, 64 at a time.  Lane l starts from the sum of the widths of the lanes
+// before it, each width read off the marker byte at that lane's assumed start; the assumption is
+// iterated to its fixed point (lane 0 is right at once, lane k after at most k more rounds; a run of
+// equal widths settles in one or two).  emit(i, v) runs on the lane that decoded value i.
+template <class Emit>
+DEVI void rds_varints(RdS &r, uint32_t cnt, Emit emit)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t done = 0, excl = lane;
+    while (done < cnt && !r.bad) {
+        const uint32_t grp = min(64u, cnt - done);
+        if (r.pos + 9 * 64 > r.w1 && r.w1 < r.len) rds_fill(r);
+        uint32_t first = 0, wd = 0, incl = 0;
+        for (int it = 0; it < 66; ++it) {
+            const uint32_t st = r.pos + excl;
+            first = (lane < grp && st < r.len) ? r.stg[st - r.w0] : 0u;
+            wd = lane >= grp ? 0u : first < 251 ? 1u : first == 251 ? 3u : first == 252 ? 5u : first == 253 ? 9u : 1u;
+            incl = wave_incl_scan_u32(wd);
+            const uint32_t ne = incl - wd;
+            const bool moved = ne != excl;
+            excl = ne;
+            if (__ballot(moved) == 0) break;
+        }
+        bool lbad = false;
+        uint64_t v = first;
+        if (lane < grp) {
+            const uint32_t st = r.pos + excl;
+            if (st + wd > r.len || first > 253) {
+                lbad = true;
+            } else if (wd > 1) {
+                v = 0;
+                for (uint32_t b = 0; b + 1 < wd; ++b) v |= (uint64_t)r.stg[st + 1 + b - r.w0] << (8 * b);
+            }
+        }
+        if (__ballot(lbad)) { r.bad = true; break; }
+        if (lane < grp) emit(done + lane, v);
+        r.pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        done += grp;
+    }
+}
+
 // PH 0: the whole decoder.  PH 1 / PH 2: the decoder around the batched inverse transform -- PH 1 parses,
 // decodes every codec but FFT completely and leaves an FFT frame's conjugated packed spectrum in buffer A
 // (DecPending in the workspace); k_large_pre1 / k_large_pre2 <DevDFrame, true> transform all pending frames
@@ -1833,7 +1874,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             (void)rds_u8(r);
             const uint64_t cnt = rds_varint(r);
             if (cnt != n) r.bad = true;
-            for (uint32_t i = 0; i < n && !r.bad; ++i) out[i] = (double)unzig(rds_varint(r));
+            if (!r.bad) rds_varints(r, n, [&](uint32_t i, uint64_t v) { out[i] = (double)unzig(v); });
             break;
         }
         case ATSC_IDW:
@@ -1851,7 +1892,9 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
                     r.pos += (uint32_t)cnt * (bd == 0 ? 8u : 1u);
                     if (r.pos > r.len) r.bad = true;
                 } else {
-                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) vals[i] = rds_value(r, bd);
+                    rds_varints(r, (uint32_t)cnt, [&](uint32_t i, uint64_t v) {
+                        vals[i] = (bd == 2) ? (double)(int16_t)unzig(v) : (double)(int32_t)unzig(v);
+                    });
                 }
             }
             h.d0 = __longlong_as_double((long long)rds_le(r, 8));
