@@ -190,7 +190,9 @@ DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_
 {
     uint32_t ncur = N, st = 1;
     while (ncur > 1) {
-        const uint32_t r = (ncur % 4 == 0) ? 4u : (ncur % 2 == 0) ? 2u : 3u;
+        // radix 9 first: two radix-3 levels in registers halve the LDS round trips, twiddle loads,
+        // index arithmetic and barriers of the 3^k part (transform lengths are 2^a 3^b, b up to 7)
+        const uint32_t r = (ncur % 9 == 0) ? 9u : (ncur % 4 == 0) ? 4u : (ncur % 2 == 0) ? 2u : 3u;
         const uint32_t m = ncur / r, nbf = N / r, sm = st * m;
         const uint32_t mg_st = st > 1 ? (uint32_t)(0x100000000ull / st) + 1u : 0u;
         const uint32_t mg_nb = nbf > 1 ? (uint32_t)(0x100000000ull / nbf) + 1u : 0u;
@@ -204,7 +206,43 @@ DEVI float2 *lds_fft(float2 *T, float2 *U, const float2 *wN, uint32_t N, uint32_
             const float2 *x = T + (q + st * p) * si + c * sq;
             float2 *y = U + (q + st * (r * p)) * si + c * sq;
             const uint32_t e = p * st;  // W_N^{e k}
-            if (r == 4) {
+            if (r == 9) {
+                // j = 3 j1 + j2, k = k1 + 3 k2:  W9^{jk} = W3^{j1 k1} W9^{j2 k1} W3^{j2 k2}
+                float2 a[9];
+#pragma unroll
+                for (uint32_t j = 0; j < 9; ++j) a[j] = x[j * sm * si];
+                auto dft3 = [](float2 &a0, float2 &a1, float2 &a2) {
+                    const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                    const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                    const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                    const float h = 0.8660254037844386f;
+                    const float2 t3 = make_float2(h * d.y, -h * d.x);
+                    a0 = make_float2(a0.x + t1.x, a0.y + t1.y);
+                    a1 = make_float2(t2.x + t3.x, t2.y + t3.y);
+                    a2 = make_float2(t2.x - t3.x, t2.y - t3.y);
+                };
+                dft3(a[0], a[3], a[6]);  // over j1, for j2 = 0, 1, 2: a[3 k1 + j2]
+                dft3(a[1], a[4], a[7]);
+                dft3(a[2], a[5], a[8]);
+                const float2 w1 = make_float2(0.766044443118978f, 0.642787609686539f);   // (cos, sin) 40 deg
+                const float2 w2 = make_float2(0.17364817766693f, 0.984807753012208f);    // 80 deg
+                const float2 w4 = make_float2(-0.939692620785908f, 0.342020143325669f);  // 160 deg
+                a[4] = cmulc(a[4], w1);  // j2 = 1, k1 = 1
+                a[7] = cmulc(a[7], w2);  // j2 = 1, k1 = 2
+                a[5] = cmulc(a[5], w2);  // j2 = 2, k1 = 1
+                a[8] = cmulc(a[8], w4);  // j2 = 2, k1 = 2
+                dft3(a[0], a[1], a[2]);  // over j2, for k1 = 0: outputs k = 0, 3, 6
+                dft3(a[3], a[4], a[5]);  // k1 = 1: k = 1, 4, 7
+                dft3(a[6], a[7], a[8]);  // k1 = 2: k = 2, 5, 8
+                y[0] = a[0];
+#pragma unroll
+                for (uint32_t k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                    for (uint32_t k2 = 0; k2 < 3; ++k2) {
+                        const uint32_t k = k1 + 3 * k2;
+                        if (k) y[k * st * si] = cmulc(a[3 * k1 + k2], wN[k * e]);
+                    }
+            } else if (r == 4) {
                 const float2 a0 = x[0], a1 = x[sm * si], a2 = x[2 * sm * si], a3 = x[3 * sm * si];
                 const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
                 const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
@@ -555,8 +593,9 @@ struct DecPending {
 };
 // pass 1: FB columns of the packed (even L) or complex (odd L) padded f32 signal.  FROM_WS: the
 // input is what the decoder left in buffer A (frames without a pending transform are skipped).
+// (8 waves per SIMD = two workgroups per CU: the register budget is 64)
 template <class FR, bool FROM_WS>
-__global__ __launch_bounds__(PT) void k_large_pre1(const double *__restrict__ samples,
+__global__ __launch_bounds__(PT, 8) void k_large_pre1(const double *__restrict__ samples,
                                                     const FR *__restrict__ frames,
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
