@@ -15,8 +15,13 @@ import numpy as np
 from tests import helpers as H
 
 FFT_COEF_RTOL = 4e-6     # relative to the largest |bin| of the frame (~32 f32 ulp)
-FFT_ERR_ATOL = 5e-6      # absolute, on MAPE: f32 transform noise plus one 5-decimal rounding flip on a short frame
+FFT_ERR_ATOL = 5e-6      # absolute, on MAPE: f32 transform noise
 FFT_ERR_RTOL = 2e-6      # relative, for the large MAPE values of frames with near-zero samples (noise / |g|)
+# Plus the decode tolerance carried into the MAPE: two correct f32 implementations may differ by
+# nu = (4 + log2 n) f32 ulp of the frame's magnitude + one step of the 5-decimal grid on a
+# reconstructed sample (the bar of the decode tests), i.e. by nu / |g| on that sample's term and by at
+# most nu * mean(1 / |g|) on the MAPE.  Short frames with a small sample show it: one grid flip on
+# g = 0.05 moves the MAPE of a 29-sample frame by 7e-6 (fuzz seeds 616, 662, 670).
 POLY_ERR_RTOL = 1e-11    # summation order only
 BOUNDARY_EPS = 5e-6
 BOUNDARY_FRAC = 0.002
@@ -35,7 +40,7 @@ def _near_threshold(err, max_error):
 
 def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, report, idx,
                   oracle_errs=None):
-    """Returns 'exact' | 'tol' | 'boundary' | 'FAIL:<why>'."""
+    """Returns 'exact' | 'tol' | 'tie' | 'boundary' | 'FAIL:<why>'."""
     if tag != chosen_o:
         errs = oracle_errs or {}
         if any(_near_threshold(e, max_error) for e in errs.values()):
@@ -68,7 +73,7 @@ def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, repor
             norms = [ng.get(p, no.get(p)) for p in diff]
             if max(norms) - min(norms) > FFT_COEF_RTOL * scale:
                 return "FAIL:fft bin set differs %s" % sorted(diff)
-            return "tol"
+            return "tie"  # different (tied) bins admitted: the reconstructions, hence the errors, differ"
         dg = {p: (r, i) for p, r, i in fg}
         for a, b in zip(pos_g, pos_o):
             if a != b:
@@ -83,6 +88,15 @@ def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, repor
                 return "FAIL:fft coef pos=%d gpu=(%r,%r) oracle=(%r,%r) scale=%r" % (
                     p, rg, ig, r, i, scale)
     return "tol"
+
+
+def fft_err_noise(fx):
+    g = np.abs(np.asarray(fx, dtype=np.float64))
+    g = g[np.isfinite(g) & (g > 0)]
+    if not g.size:
+        return 0.0
+    nu = (4 + np.log2(max(len(fx), 2))) * float(g.max()) * 2.0 ** -23 + 1.00001e-5
+    return nu * float(np.mean(1.0 / g)) * g.size / len(fx)
 
 
 def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, want_diag=True):
@@ -118,11 +132,14 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
         summary["codecs"][tag] = summary["codecs"].get(tag, 0) + 1
         if verdict.startswith("FAIL"):
             summary["fail"].append((i, verdict))
+        elif verdict == "tie":
+            summary["tol"] += 1
         else:
             summary[verdict] += 1
             if verdict != "boundary":
                 # reported error: exact codecs report 0.0; lossy within tolerance
-                tol = (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo)) if tag == oracle.FFT else max(POLY_ERR_RTOL * abs(eo), 1e-300)
+                tol = (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo) + fft_err_noise(fx)) if tag == oracle.FFT \
+                    else max(POLY_ERR_RTOL * abs(eo), 1e-300)
                 if not (err[i] == eo or abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
                     summary["fail"].append((i, "FAIL:err gpu=%r oracle=%r" % (err[i], eo)))
     return summary
