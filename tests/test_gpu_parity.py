@@ -832,3 +832,56 @@ def test_host_entry_points_reuse_device_memory(ctx, A):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def _record(tag, n, payload):
+    """One frame record of a .bro body (frame/mod.rs:57-66 via bincode): size, samples, codec, payload."""
+    return P.H_varint(41) + P.H_varint(n) + P.H_varint(tag) + P.H_varint(len(payload)) + payload
+
+
+def test_decompress_large_foreign_fft_streams(ctx, A, oracle):
+    """FFT payloads this library's encoder never writes, decoded like the oracle decodes them: more entries
+    than the ladder can store (the decoder's serial parse + dense transform), duplicate positions (later
+    entries overwrite), positions above L/2 (mirrored), entries of both widths in one stream."""
+    import struct
+    rng = np.random.default_rng(77)
+    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500)):
+        L = int(oracle.next_size(n))
+        pos = rng.integers(0, L, size=cnt)
+        pos[: cnt // 3] = rng.integers(0, 251, size=cnt // 3)          # one-byte positions among the wide ones
+        pos[cnt // 2: cnt // 2 + 20] = pos[:20]                          # duplicates: the later entry wins
+        re = rng.normal(0, 50.0, size=cnt).astype(np.float32)
+        im = rng.normal(0, 50.0, size=cnt).astype(np.float32)
+        pay = bytes([15]) + P.H_varint(cnt)
+        for p, r, i in zip(pos, re, im):
+            pay += P.H_varint(int(p)) + struct.pack("<ff", r, i)
+        pay += struct.pack("<ff", 40.0, -40.0)
+        ref = np.array(oracle.decompress(oracle.FFT, pay, n))
+        out = ctx.decompress_host(_record(oracle.FFT, n, pay))
+        assert len(out) == n
+        scale = max(float(np.max(np.abs(re))), 1.0) * cnt / L
+        tol = (4 + np.log2(n)) * max(scale, 40.0) * 2.0 ** -23 + 1.00001e-5
+        assert np.max(np.abs(out - ref)) <= tol, (n, cnt, float(np.max(np.abs(out - ref))), tol)
+
+
+def test_decompress_large_mixed_width_varints(ctx, A, oracle):
+    """Polynomial points and Noop values whose zigzag varints mix 1-, 3-, 5- and 9-byte widths at random:
+    the 64-at-a-time parse has to settle lane by lane; decode must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(78)
+    for n in (4097, 9000, 40000):
+        # Noop: integers around the 251 marker and the 16/32-bit boundaries
+        pool = np.array([0, 1, -1, 124, 125, 126, -125, -126, -127, 300, -300, 32767, -32768, 32768, 70000, -70000,
+                         2 ** 31 - 1, -2 ** 31, 2 ** 31, 2 ** 40, -2 ** 40], dtype=np.float64)
+        x = rng.choice(pool, size=n)
+        po, _ = oracle.compress(A.NOOP, x, False, 0.0)
+        ref = np.array(oracle.decompress(A.NOOP, po, n))
+        out = ctx.decompress_host(_record(A.NOOP, n, po))
+        assert np.array_equal(out, ref), ("noop", n)
+        # Polynomial with i16 / i32 points of mixed widths
+        for lim in (200, 40000):
+            x = np.round(rng.uniform(-lim, lim, size=n))
+            x[rng.integers(0, n, size=n // 7)] = rng.integers(-3, 4, size=n // 7)
+            po, _ = oracle.compress(A.POLYNOMIAL, x, True, 0.5)
+            ref = np.array(oracle.decompress(A.POLYNOMIAL, po, n))
+            out = ctx.decompress_host(_record(A.POLYNOMIAL, n, po))
+            assert np.array_equal(out, ref), ("poly", n, lim)
