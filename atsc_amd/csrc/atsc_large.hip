@@ -1032,6 +1032,183 @@ __global__ __launch_bounds__(LT) void k_compress_large(
 
     if (prm.debug_stop == 2) return;
     // =========================================================================================
+    // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
+    // interpolation (polynomial.rs:375-393)
+    // =========================================================================================
+    // The ladder runs in two goes: its first trip before the FFT candidate, the rest after it.  A frame
+    // whose polynomial passes at once with fewer bytes than the FFT's first trip could store never
+    // builds the admission order or runs an inverse transform; otherwise the later trips are pruned by
+    // the FFT's size exactly as before.  Pruning only skips candidates that cannot win, so the
+    // selection does not depend on the order (frame/mod.rs:113-138).
+    uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
+    double poly_err = 0.0;
+    bool poly_done = false, poly_pruned = false, poly_active = false;
+    double pcur = prm.max_err + 1.0;
+    uint32_t pjump = 0;
+    auto poly_ladder = [&](uint32_t limit) {
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
+            double cur = pcur;
+            uint32_t jump = pjump, done_now = 0;
+            while (true) {
+                if (!(round(cur * 10000.0) > prm.poly_q_hi)) { poly_active = false; break; }
+                if (done_now == limit) break;
+                ++done_now;
+                const uint32_t pts = base + jump;
+                const uint32_t step = max(n / pts, 1u);
+                const uint32_t cnt = (n + step - 1) / step;
+                const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                // payload of this trip, exactly (F64 / U8 points) or from below (>= 1 byte per varint)
+                if (prune && !can_win(2 + vlen(K) + K * (bitdepth == 0 ? 8u : 1u) + 17, 1)) { poly_pruned = true; poly_active = false; break; }
+                ++poly_trips;
+                poly_step = step;
+                poly_K = K;
+                if (idw && step > 1) {
+                    // inverse_distance_weight 0.1.1, power 2 (oracle: poly_idw_to_data): a sample that
+                    // sits on a point takes its value, every other sample sums w = 1 / d^2 over ALL K
+                    // points in ascending order.  d is an integer, so the weights come from a per-frame
+                    // table w[d] = 1.0 / (d * d) kept in the (idle) FFT buffer: O(n K) FMAs per trip.
+                    double *wtab = (double *)A;
+                    if (poly_trips == 1) {
+                        for (uint32_t d = tid + 1; d < n; d += T) {
+                            const double dd = (double)d;
+                            wtab[d] = 1.0 / (dd * dd);
+                        }
+                        __syncthreads();
+                    }
+                    double s = 0.0;
+                    for (uint32_t i = tid; i < n; i += T) {
+                        double sv;
+                        const uint32_t q = i / step;
+                        if (i == n - 1 || (q * step == i && q < K - 1)) {
+                            sv = xs[i];
+                        } else {
+                            double num = 0.0, den = 0.0;
+                            for (uint32_t k = 0; k < K; ++k) {
+                                const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
+                                const double w = wtab[pk > i ? pk - i : i - pk];
+                                num += w * xs[pk];
+                                den += w;
+                            }
+                            sv = num / den;
+                        }
+                        double o = div1e5(round(sv * 100000.0));
+                        if (o < smin) o = smin;
+                        else if (o > smax) o = smax;
+                        const double g = xs[i];
+                        s += fabs((o - g) / g);
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                } else if (step > 1) {
+                    const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+                    const uint32_t gapL = (n - 1) - (K - 2) * step;
+                    const double stepd = (double)step, gapLd = (double)gapL;
+                    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+                    __syncthreads();
+                    for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
+                        const uint32_t t0i = sg * step;
+                        const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                        const uint32_t tmi = (sg - 1) * step;
+                        const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                        const double t0 = (double)t0i, t1 = (double)t1i;
+                        const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+                        double2 t;
+                        t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                        t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                        mm[sg] = t;
+                    }
+                    for (uint32_t r = tid; r < step; r += T) {  // step <= 133: Hermite basis per offset
+                        const double nt = div_small((double)r, stepd, ry);
+                        const double t2 = nt * nt;
+                        const double t3 = t2 * nt;
+                        const double two_t3 = t3 * 2.0;
+                        const double two_t2 = t2 * 2.0;
+                        const double three_t2 = t2 * 3.0;
+                        double4 h;
+                        h.x = two_t3 - three_t2 + 1.0;
+                        h.y = t3 - two_t2 + nt;
+                        h.z = three_t2 - two_t3;
+                        h.w = t3 - t2;
+                        hbt[r] = h;
+                    }
+                    __syncthreads();
+                    double s = 0.0;
+                    for (uint32_t i = tid; i < n; i += T) {
+                        double sv;
+                        if (i == n - 1) {
+                            sv = xs[n - 1];
+                        } else {
+                            uint32_t sg = __umulhi(i, magic);
+                            if (sg > K - 2) sg = K - 2;
+                            const uint32_t t0i = sg * step;
+                            const bool last = (sg == K - 2);
+                            const uint32_t t1i = last ? (n - 1) : t0i + step;
+                            const double v0 = xs[t0i], v1 = xs[t1i];
+                            if (sg > 0 && !last) {
+                                const double2 t = mm[sg];
+                                const double4 h = hbt[i - t0i];
+                                sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
+                            } else {
+                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                            last ? ryL : ry);
+                                sv = v0 * (1.0 - nt) + v1 * nt;
+                            }
+                        }
+                        double o = div1e5(round(sv * 100000.0));
+                        if (o < smin) o = smin;
+                        else if (o > smax) o = smax;
+                        const double g = xs[i];
+                        s += fabs((o - g) / g);
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                }
+                if (poly_trips <= 17) jump += dj1;
+                else if (poly_trips <= 22) jump += dj2;
+                else if (round(cur * 10000.0) < prm.poly_q_lo) { poly_active = false; break; }
+                else { poly_step = 1; poly_K = n; cur = 0.0; poly_active = false; break; }
+                if (K == n) { cur = 0.0; poly_active = false; break; }
+            }
+            pcur = cur;
+            pjump = jump;
+            poly_err = cur;
+    };
+    auto poly_finish = [&]() {
+        uint32_t vb = 0;
+        if (bitdepth == 0 || bitdepth == 3) {
+            vb = poly_K * (bitdepth == 0 ? 8u : 1u);
+        } else {
+            for (uint32_t k = tid; k < poly_K; k += T) {
+                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
+                vb += value_bytes(bitdepth, xs[t]);
+            }
+            vb = block_sum_u32<W>(vb, red, parity);
+        }
+        poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
+        poly_done = !poly_pruned;
+        if (prune && poly_done && poly_err <= me) offer(poly_size, 1);
+        dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
+        dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
+    };
+    if (run_poly) {
+        if (smax == smin) {
+            poly_K = 0;
+            poly_step = 1;
+        } else if (!prm.bounded) {
+            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+            poly_step = max(n / base, 1u);
+            const uint32_t cnt = (n + poly_step - 1) / poly_step;
+            poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
+        } else {
+            poly_active = true;
+            poly_ladder(1);
+        }
+        if (!poly_active) poly_finish();
+    }
+
+
+    // =========================================================================================
     // FFT candidate (fft.rs:288-362)
     // =========================================================================================
     uint32_t fft_k = 0, fft_size = 0xFFFFFFFFu, fft_trips = 0;
@@ -1235,7 +1412,13 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             __syncthreads();
             return nkeys;
             };
-            uint32_t nkeys = build_order(min(kcap_total, max(4096u, P.mf + 4 * P.dk1)));
+            // the first trip stores min(mf, Z) bins: if even that payload loses to a candidate that
+            // already passes (the polynomial's first trip ran before this block), neither the order nor
+            // the ladder is needed
+            const uint32_t K1 = min(P.mf, Z);
+            const bool fft_hopeless = prune && !can_win(1 + vlen(K1) + 9 * K1 + 8, 0);
+            if (fft_hopeless) fft_pruned = true;
+            uint32_t nkeys = fft_hopeless ? 0u : build_order(min(kcap_total, max(4096u, P.mf + 4 * P.dk1)));
             if (prm.debug_stop == 5) return;
 
             // ---- ladder ----
@@ -1251,7 +1434,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             const float Lf = (float)L;
             uint32_t used = 0, jump = 0;
             double cur = prm.max_err + 1.0;
-            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
+            while (!fft_hopeless && (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0))) {
                 uint32_t K = min(P.mf + jump, Z);
                 if (K > nkeys && nkeys < min(kcap_total, bins)) nkeys = build_order(kcap_total);  // same prefix, longer
                 K = min(K, nkeys);
@@ -1371,161 +1554,10 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
 
     if (prm.debug_stop == 6 || prm.debug_stop >= 16) return;
-    // =========================================================================================
-    // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
-    // interpolation (polynomial.rs:375-393)
-    // =========================================================================================
-    uint32_t poly_step = 1, poly_K = 0, poly_size = 0xFFFFFFFFu, poly_trips = 0;
-    double poly_err = 0.0;
-    bool poly_done = false, poly_pruned = false;
-    if (run_poly) {
-        if (smax == smin) {
-            poly_K = 0;
-            poly_step = 1;
-        } else if (!prm.bounded) {
-            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-            poly_step = max(n / base, 1u);
-            const uint32_t cnt = (n + poly_step - 1) / poly_step;
-            poly_K = cnt + (((cnt - 1) * poly_step != n - 1) ? 1u : 0u);
-        } else {
-            const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
-            const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
-            double cur = prm.max_err + 1.0;
-            uint32_t jump = 0;
-            while (round(cur * 10000.0) > prm.poly_q_hi) {
-                const uint32_t pts = base + jump;
-                const uint32_t step = max(n / pts, 1u);
-                const uint32_t cnt = (n + step - 1) / step;
-                const uint32_t K = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
-                // payload of this trip, exactly (F64 / U8 points) or from below (>= 1 byte per varint)
-                if (prune && !can_win(2 + vlen(K) + K * (bitdepth == 0 ? 8u : 1u) + 17, 1)) { poly_pruned = true; break; }
-                ++poly_trips;
-                poly_step = step;
-                poly_K = K;
-                if (idw && step > 1) {
-                    // inverse_distance_weight 0.1.1, power 2 (oracle: poly_idw_to_data): a sample that
-                    // sits on a point takes its value, every other sample sums w = 1 / d^2 over ALL K
-                    // points in ascending order.  d is an integer, so the weights come from a per-frame
-                    // table w[d] = 1.0 / (d * d) kept in the (idle) FFT buffer: O(n K) FMAs per trip.
-                    double *wtab = (double *)A;
-                    if (poly_trips == 1) {
-                        for (uint32_t d = tid + 1; d < n; d += T) {
-                            const double dd = (double)d;
-                            wtab[d] = 1.0 / (dd * dd);
-                        }
-                        __syncthreads();
-                    }
-                    double s = 0.0;
-                    for (uint32_t i = tid; i < n; i += T) {
-                        double sv;
-                        const uint32_t q = i / step;
-                        if (i == n - 1 || (q * step == i && q < K - 1)) {
-                            sv = xs[i];
-                        } else {
-                            double num = 0.0, den = 0.0;
-                            for (uint32_t k = 0; k < K; ++k) {
-                                const uint32_t pk = (k == K - 1) ? (n - 1) : k * step;
-                                const double w = wtab[pk > i ? pk - i : i - pk];
-                                num += w * xs[pk];
-                                den += w;
-                            }
-                            sv = num / den;
-                        }
-                        double o = div1e5(round(sv * 100000.0));
-                        if (o < smin) o = smin;
-                        else if (o > smax) o = smax;
-                        const double g = xs[i];
-                        s += fabs((o - g) / g);
-                    }
-                    s = block_sum_f64<W>(s, red, parity);
-                    cur = s / (double)n;
-                } else if (step > 1) {
-                    const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
-                    const uint32_t gapL = (n - 1) - (K - 2) * step;
-                    const double stepd = (double)step, gapLd = (double)gapL;
-                    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
-                    __syncthreads();
-                    for (uint32_t sg = tid + 1; sg + 2 < K; sg += T) {
-                        const uint32_t t0i = sg * step;
-                        const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
-                        const uint32_t tmi = (sg - 1) * step;
-                        const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
-                        const double t0 = (double)t0i, t1 = (double)t1i;
-                        const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
-                        double2 t;
-                        t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
-                        t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
-                        mm[sg] = t;
-                    }
-                    for (uint32_t r = tid; r < step; r += T) {  // step <= 133: Hermite basis per offset
-                        const double nt = div_small((double)r, stepd, ry);
-                        const double t2 = nt * nt;
-                        const double t3 = t2 * nt;
-                        const double two_t3 = t3 * 2.0;
-                        const double two_t2 = t2 * 2.0;
-                        const double three_t2 = t2 * 3.0;
-                        double4 h;
-                        h.x = two_t3 - three_t2 + 1.0;
-                        h.y = t3 - two_t2 + nt;
-                        h.z = three_t2 - two_t3;
-                        h.w = t3 - t2;
-                        hbt[r] = h;
-                    }
-                    __syncthreads();
-                    double s = 0.0;
-                    for (uint32_t i = tid; i < n; i += T) {
-                        double sv;
-                        if (i == n - 1) {
-                            sv = xs[n - 1];
-                        } else {
-                            uint32_t sg = __umulhi(i, magic);
-                            if (sg > K - 2) sg = K - 2;
-                            const uint32_t t0i = sg * step;
-                            const bool last = (sg == K - 2);
-                            const uint32_t t1i = last ? (n - 1) : t0i + step;
-                            const double v0 = xs[t0i], v1 = xs[t1i];
-                            if (sg > 0 && !last) {
-                                const double2 t = mm[sg];
-                                const double4 h = hbt[i - t0i];
-                                sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
-                            } else {
-                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
-                                                            last ? ryL : ry);
-                                sv = v0 * (1.0 - nt) + v1 * nt;
-                            }
-                        }
-                        double o = div1e5(round(sv * 100000.0));
-                        if (o < smin) o = smin;
-                        else if (o > smax) o = smax;
-                        const double g = xs[i];
-                        s += fabs((o - g) / g);
-                    }
-                    s = block_sum_f64<W>(s, red, parity);
-                    cur = s / (double)n;
-                }
-                if (poly_trips <= 17) jump += dj1;
-                else if (poly_trips <= 22) jump += dj2;
-                else if (round(cur * 10000.0) < prm.poly_q_lo) break;
-                else { poly_step = 1; poly_K = n; cur = 0.0; break; }
-                if (K == n) { cur = 0.0; break; }
-            }
-            poly_err = cur;
-        }
-        uint32_t vb = 0;
-        if (bitdepth == 0 || bitdepth == 3) {
-            vb = poly_K * (bitdepth == 0 ? 8u : 1u);
-        } else {
-            for (uint32_t k = tid; k < poly_K; k += T) {
-                const uint32_t t = (k == poly_K - 1) ? (n - 1) : k * poly_step;
-                vb += value_bytes(bitdepth, xs[t]);
-            }
-            vb = block_sum_u32<W>(vb, red, parity);
-        }
-        poly_size = 1 + 1 + vlen(poly_K) + vb + 8 + 8 + 1;
-        poly_done = !poly_pruned;
-        if (prune && poly_done && poly_err <= me) offer(poly_size, 1);
-        dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
-        dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
+    // the polynomial ladder continues where its first trip stopped (see above the FFT block)
+    if (run_poly && poly_active) {
+        poly_ladder(0xFFFFFFFFu);
+        poly_finish();
     }
 
     if (prm.debug_stop == 7) return;
