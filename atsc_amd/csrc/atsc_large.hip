@@ -961,14 +961,45 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     auto run_key = [&](uint64_t rec) { return (uint64_t)__double_as_longlong(xs[(uint32_t)rec]); };
     auto rle_sort_and_group = [&]() {
         __syncthreads();
+        uint32_t R;
+        uint32_t *ends = rhp;
+        if (rle_R <= 8192) {
+            // The run count is known from the statistics.  Each wavefront walks one contiguous sixteenth
+            // of the frame, 64 samples at a time, and appends its run ends in order (ballot ranks) to its
+            // own stretch of a scratch list; the stretches are then laid end to end.  One coalesced pass
+            // over the samples instead of a flag array, a scan over n and a scatter.
+            const uint32_t lane = tid & 63u, wv = tid >> 6;
+            const uint32_t seg = (((n + W - 1) / W) + 63u) & ~63u;
+            const uint32_t s0 = min(wv * seg, n), s1 = min(s0 + seg, n);
+            uint32_t *mine = (uint32_t *)tab + wv * min(seg, 8192u);  // <= 4 n + 4 KB of the (idle) hash-table region
+            const uint64_t lt = (1ull << lane) - 1ull;
+            uint32_t cnt = 0;
+            for (uint32_t j0 = s0; j0 < s1; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool fl = j < s1 && (j + 1 >= n || xs[j + 1] != xs[j]);
+                const uint64_t m = __ballot(fl);
+                if (fl) mine[cnt + (uint32_t)__popcll(m & lt)] = j;
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) wsum[wv] = cnt;
+            __syncthreads();
+            uint32_t base = 0;
+            R = 0;
+            for (uint32_t w2 = 0; w2 < (uint32_t)W; ++w2) {
+                if (w2 < wv) base += wsum[w2];
+                R += wsum[w2];
+            }
+            for (uint32_t k = lane; k < cnt; k += 64) ends[base + k] = mine[k];
+            __syncthreads();
+        } else {
         for (uint32_t j = tid; j < n; j += T)
             aux[j] = (j + 1 >= n || xs[j + 1] != xs[j]) ? 1u : 0u;
         __syncthreads();
-        const uint32_t R = lscan(aux, n, wsum);
-        uint32_t *ends = rhp;
+        R = lscan(aux, n, wsum);
         for (uint32_t j = tid; j < n; j += T)
             if (j + 1 >= n || xs[j + 1] != xs[j]) ends[aux[j]] = j;
         __syncthreads();
+        }
         for (uint32_t r = tid; r < R; r += T) {
             const uint32_t st = r ? ends[r - 1] + 1 : 0;
             rrec[r] = ((uint64_t)st << 32) | ends[r];
