@@ -1,8 +1,8 @@
 // atsc_decode.hip -- gfx950 kernels for CompressorFrame::decompress (atsc/src/frame/mod.rs:152-158
 // -> Compressor::decompress, atsc/src/compressor/mod.rs:109-119).
 //
-// One workgroup of W wavefronts per frame.  The payload header is walked by lane 0 (varint
-// fields are sequential by construction); the per-sample reconstruction is parallel:
+// One workgroup of W wavefronts per frame.  The payload is walked by the first wavefront through an
+// LDS window (varint fields are sequential by construction); the per-sample reconstruction is parallel:
 //   FFT         fft.rs:426-462      K-sparse Hermitian spectrum -> direct sum over the stored bins
 //                                   (f64 accumulation, f32 table twiddles), f32 result / L, round 5, clamp
 //   Polynomial  polynomial.rs:395-404,342-373  Catmull-Rom/linear pieces, exact f64 op order
@@ -42,67 +42,93 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
     };
     Hdr *hdr = (Hdr *)(red + 40);
 
-    if (tid == 0) {
-        Rd r{pay, fr.payload_len, 0, false};
+    // The first wavefront walks the payload in lock step (every lane computes and writes the same
+    // values) through an LDS window refilled by its 64 lanes -- the twiddle region, idle until the header is
+    // known -- instead of one lane pulling bytes out of global memory one dependent read at a time.  Runs of
+    // variable-width fields are parsed 64 at a time when the window holds a whole group (atsc_device.h).
+    if (tid < 64) {
+        const uint32_t cap = (P.o_ab - P.o_tw) & ~15u;
+        RdS r{pay, fr.payload_len, 0, false, smem + P.o_tw, 0, 0, cap};
+        const bool wide = cap >= 11 * 64 + 16;
         Hdr h;
         h.d0 = h.d1 = 0.0; h.u0 = h.u1 = h.u2 = 0; h.f0 = h.f1 = 0.0f;
         switch (fr.tag) {
         case ATSC_CONSTANT: {
-            (void)rd_u8(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
             if (bd > 3) r.bad = true;
-            else h.d0 = rd_value(r, bd);
+            else h.d0 = rds_value(r, bd);
             break;
         }
         case ATSC_NOOP: {
-            (void)rd_u8(r);
-            const uint64_t cnt = rd_varint(r);
+            (void)rds_u8(r);
+            const uint64_t cnt = rds_varint(r);
             if (cnt != n) r.bad = true;
-            for (uint32_t i = 0; i < n && !r.bad; ++i) xs[i] = (double)unzig(rd_varint(r));
+            if (r.bad) break;
+            if (wide) rds_varints(r, n, [&](uint32_t i, uint64_t v) { xs[i] = (double)unzig(v); });
+            else for (uint32_t i = 0; i < n && !r.bad; ++i) xs[i] = (double)unzig(rds_varint(r));
             break;
         }
         case ATSC_IDW:
         case ATSC_POLYNOMIAL: {
-            const uint32_t id = (uint32_t)rd_varint(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
-            const uint64_t cnt = rd_varint(r);
+            const uint32_t id = (uint32_t)rds_varint(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t cnt = rds_varint(r);
             if (id > 1 || bd > 3 || cnt > n) r.bad = true;
             h.u2 = id;  // PolynomialType decides the interpolation (polynomial.rs:400-403), not the frame tag
-            for (uint32_t i = 0; i < cnt && !r.bad; ++i) xs[i] = rd_value(r, bd);
-            h.d0 = __longlong_as_double((long long)rd_le(r, 8));  // min
-            h.d1 = __longlong_as_double((long long)rd_le(r, 8));  // max
+            if (!r.bad) {
+                if (wide && (bd == 1 || bd == 2)) {
+                    rds_varints(r, (uint32_t)cnt, [&](uint32_t i, uint64_t v) {
+                        xs[i] = (bd == 2) ? (double)(int16_t)unzig(v) : (double)(int32_t)unzig(v);
+                    });
+                } else {
+                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) xs[i] = rds_value(r, bd);
+                }
+            }
+            h.d0 = __longlong_as_double((long long)rds_le(r, 8));  // min
+            h.d1 = __longlong_as_double((long long)rds_le(r, 8));  // max
             h.u0 = (uint32_t)cnt;
-            h.u1 = rd_u8(r);  // point_step
+            h.u1 = rds_u8(r);  // point_step
             break;
         }
         case ATSC_FFT: {
-            (void)rd_u8(r);
-            const uint64_t cnt = rd_varint(r);
+            (void)rds_u8(r);
+            const uint64_t cnt = rds_varint(r);
             if (cnt > P.bins) r.bad = true;
             Sel *sel = (Sel *)AB;
-            for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
-                sel[i].pos = (uint32_t)rd_varint(r) & 0xffffu;
-                sel[i].re = rd_f32(r);
-                sel[i].im = rd_f32(r);
+            if (!r.bad) {
+                if (wide) {
+                    rds_fft_entries(r, (uint32_t)cnt, P.L, sel);
+                } else {
+                    for (uint32_t i = 0; i < cnt && !r.bad; ++i) {
+                        uint32_t pos = (uint32_t)rds_varint(r) & 0xffffu;
+                        const float re = rds_f32(r);
+                        float im = rds_f32(r);
+                        if (pos >= P.L) { r.bad = true; break; }
+                        if (pos > P.L / 2) { pos = P.L - pos; im = -im; }  // fft.rs:401-422
+                        if (pos == 0 || 2 * pos == P.L) im = 0.0f;
+                        sel[i].pos = pos; sel[i].re = re; sel[i].im = im;
+                    }
+                }
             }
             h.u0 = (uint32_t)cnt;
-            h.f0 = rd_f32(r);  // max_value
-            h.f1 = rd_f32(r);  // min_value
+            h.f0 = rds_f32(r);  // max_value
+            h.f1 = rds_f32(r);  // min_value
             break;
         }
         case ATSC_RLE: {
-            (void)rd_u8(r);
-            const uint32_t bd = (uint32_t)rd_varint(r);
-            const uint64_t groups = rd_varint(r);
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t groups = rds_varint(r);
             if (bd > 3 || groups > n) r.bad = true;
             uint64_t *keys = (uint64_t *)AB;  // (run start << 32) | group
             uint32_t e = 0;
             for (uint32_t gi = 0; gi < groups && !r.bad; ++gi) {
-                xs[gi] = rd_value(r, bd);
-                const uint64_t cnt = rd_varint(r);
+                xs[gi] = rds_value(r, bd);
+                const uint64_t cnt = rds_varint(r);
                 if (cnt > n - e) { r.bad = true; break; }
                 for (uint32_t k = 0; k < cnt && !r.bad; ++k) {
-                    const uint64_t idx = rd_varint(r);
+                    const uint64_t idx = rds_varint(r);
                     if (idx >= n) { r.bad = true; break; }
                     keys[e++] = (idx << 32) | gi;
                 }
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         }
         h.bad = r.bad ? 1u : 0u;
         *hdr = h;
-        if (r.bad) atomicExch(status, 1);
+        if (r.bad && tid == 0) atomicExch(status, 1);
     }
     __syncthreads();
     const Hdr h = *hdr;
@@ -187,28 +213,55 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         __syncthreads();
         const Sel *sel = (const Sel *)AB;
         const uint32_t K = h.u0;
+        // entries are applied in stream order, later ones overwrite (fft.rs:401-422): the last entry naming
+        // a (mirrored) position owns it
+        uint32_t *own = aux;  // bins = L/2 + 1 <= n + 2 words
+        for (uint32_t k = tid; k <= L / 2; k += T) own[k] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += T) atomicMax(&own[sel[i].pos], i + 1);
+        __syncthreads();
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
-        for (uint32_t j = tid; j < n; j += T) {
-            const uint32_t jj = j + pre;
-            double acc = 0.0;
-            for (uint32_t i = 0; i < K; ++i) {
-                const uint32_t pos = sel[i].pos;
-                if (pos >= L) continue;
-                const double re = (double)sel[i].re, im = (double)sel[i].im;
-                if (pos == 0) {
-                    acc += re;
-                } else {
-                    const float2 w = tw[(uint32_t)(((uint64_t)pos * jj) % L)];
-                    const double cf = (2 * pos == L) ? 1.0 : 2.0;  // fft.rs:401-422
-                    acc += cf * (re * (double)w.x - im * (double)w.y);
-                }
+        const uint32_t magicL = P.magicL;
+        // A thread owns samples tid, tid + T, ... (at most MAXS of them: n <= 576 W); the entries are the
+        // outer loop so that an entry's constants and its twiddle index walk (pos * (j + pre) mod L,
+        // advanced by pos * T mod L) are set up once.  Per sample the terms still add up in stream order,
+        // and 2 (re wx - im wy) = (2 re) wx - (2 im) wy exactly, so the sums are those of the sample-outer form.
+        constexpr int MAXS = 9;
+        double acc[MAXS];
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) acc[m] = 0.0;
+        for (uint32_t i = 0; i < K; ++i) {
+            const Sel e = sel[i];
+            const uint32_t pos = e.pos;
+            if (own[pos] != i + 1) continue;
+            if (pos == 0) {
+#pragma unroll
+                for (int m = 0; m < MAXS; ++m) acc[m] += (double)e.re;
+                continue;
             }
-            const float v = (float)acc / Lf;  // fft.rs:460  f.re / len (f32)
-            double o = round((double)v * 100000.0) / 100000.0;  // fft.rs:208-218 (max first)
-            if (o > mxd) o = mxd;
-            if (o < mnd) o = mnd;
-            out[j] = o;
+            const double cf = (2 * pos == L) ? 1.0 : 2.0;  // fft.rs:401-422
+            const double a = cf * (double)e.re, bq = cf * (double)e.im;
+            uint32_t idx = mod_magic(pos * (tid + pre), L, magicL);  // pos * jj < 2^32
+            const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
+#pragma unroll
+            for (int m = 0; m < MAXS; ++m) {
+                const float2 w = tw[idx];
+                acc[m] += a * (double)w.x - bq * (double)w.y;
+                idx += stp;
+                idx = min(idx, idx - L);  // idx < 2L: the unsigned wrap picks the reduced value
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) {
+            const uint32_t j = tid + m * T;
+            if (j < n) {
+                const float v = (float)acc[m] / Lf;  // fft.rs:460  f.re / len (f32)
+                double o = round((double)v * 100000.0) / 100000.0;  // fft.rs:208-218 (max first)
+                if (o > mxd) o = mxd;
+                if (o < mnd) o = mnd;
+                out[j] = o;
+            }
         }
         return;
     }

@@ -1786,107 +1786,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
 // --------------------------------------------------------------------------------------------
 // k_decompress_large: CompressorFrame::decompress for frames of 4097 .. 131072 samples
 // --------------------------------------------------------------------------------------------
-// Payload reader of the large decoder.  A payload's varint fields are sequential by construction (up to
-// 13100 FFT entries, 131072 Noop values), and a byte at a time out of global memory costs a memory round
-// trip per dependent read.  The first wavefront walks the payload in lock step (every lane computes the
-// same thing) and keeps a 16 KB window of it in LDS, refilled by the 64 lanes together.
-constexpr uint32_t STG_BYTES = 16384;
-struct RdS {
-    const uint8_t *g;  // payload in global memory
-    uint32_t len, pos;
-    bool bad;
-    uint8_t *stg;      // LDS window of STG_BYTES
-    uint32_t w0, w1;   // payload bytes [w0, w1) are staged
-};
-DEVI void rds_fill(RdS &r)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    r.w0 = r.pos;
-    const uint32_t nbytes = min(r.len - r.w0, STG_BYTES);
-    for (uint32_t o = lane * 4; o < nbytes; o += 64 * 4) {  // byte-granular source alignment: 4 bytes per lane
-        uint32_t v = 0;
-        const uint32_t left = min(nbytes - o, 4u);
-        for (uint32_t b = 0; b < left; ++b) v |= (uint32_t)r.g[r.w0 + o + b] << (8 * b);
-        *(uint32_t *)(r.stg + o) = v;
-    }
-    r.w1 = r.w0 + nbytes;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-DEVI uint32_t rds_u8(RdS &r)
-{
-    if (r.pos + 1 > r.len) { r.bad = true; return 0; }
-    if (r.pos >= r.w1) rds_fill(r);
-    return r.stg[r.pos++ - r.w0];
-}
-DEVI uint64_t rds_le(RdS &r, uint32_t nb)
-{
-    if (r.pos + nb > r.len) { r.bad = true; return 0; }
-    if (r.pos + nb > r.w1) rds_fill(r);  // nb <= 8 << window
-    uint64_t v = 0;
-    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)r.stg[r.pos + i - r.w0] << (8 * i);
-    r.pos += nb;
-    return v;
-}
-DEVI uint64_t rds_varint(RdS &r)
-{
-    const uint32_t t = rds_u8(r);
-    if (t < 251) return t;
-    if (t == 251) return rds_le(r, 2);
-    if (t == 252) return rds_le(r, 4);
-    if (t == 253) return rds_le(r, 8);
-    r.bad = true;
-    return 0;
-}
-DEVI double rds_value(RdS &r, uint32_t bd)
-{
-    if (bd == 3) return (double)rds_u8(r);
-    if (bd == 2) return (double)(int16_t)unzig(rds_varint(r));
-    if (bd == 1) return (double)(int32_t)unzig(rds_varint(r));
-    return __longlong_as_double((long long)rds_le(r, 8));
-}
-DEVI float rds_f32(RdS &r) { return __uint_as_float((uint32_t)rds_le(r, 4)); }
-
-// `cnt` consecutive varints, 64 at a time.  Lane l starts from the sum of the widths of the lanes
-// before it, each width read off the marker byte at that lane's assumed start; the assumption is
-// iterated to its fixed point (lane 0 is right at once, lane k after at most k more rounds; a run of
-// equal widths settles in one or two).  emit(i, v) runs on the lane that decoded value i.
-template <class Emit>
-DEVI void rds_varints(RdS &r, uint32_t cnt, Emit emit)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t done = 0, excl = lane;
-    while (done < cnt && !r.bad) {
-        const uint32_t grp = min(64u, cnt - done);
-        if (r.pos + 9 * 64 > r.w1 && r.w1 < r.len) rds_fill(r);
-        uint32_t first = 0, wd = 0, incl = 0;
-        for (int it = 0; it < 66; ++it) {
-            const uint32_t st = r.pos + excl;
-            first = (lane < grp && st < r.len) ? r.stg[st - r.w0] : 0u;
-            wd = lane >= grp ? 0u : first < 251 ? 1u : first == 251 ? 3u : first == 252 ? 5u : first == 253 ? 9u : 1u;
-            incl = wave_incl_scan_u32(wd);
-            const uint32_t ne = incl - wd;
-            const bool moved = ne != excl;
-            excl = ne;
-            if (__ballot(moved) == 0) break;
-        }
-        bool lbad = false;
-        uint64_t v = first;
-        if (lane < grp) {
-            const uint32_t st = r.pos + excl;
-            if (st + wd > r.len || first > 253) {
-                lbad = true;
-            } else if (wd > 1) {
-                v = 0;
-                for (uint32_t b = 0; b + 1 < wd; ++b) v |= (uint64_t)r.stg[st + 1 + b - r.w0] << (8 * b);
-            }
-        }
-        if (__ballot(lbad)) { r.bad = true; break; }
-        if (lane < grp) emit(done + lane, v);
-        r.pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        done += grp;
-    }
-}
+constexpr uint32_t STG_BYTES = 16384;  // payload window of the large decoder (RdS, atsc_device.h)
 
 // PH 0: the whole decoder.  PH 1 / PH 2: the decoder around the batched inverse transform -- PH 1 parses,
 // decodes every codec but FFT completely and leaves an FFT frame's conjugated packed spectrum in buffer A
@@ -1961,7 +1861,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     __syncthreads();
 
     if (tid < 64) {  // the first wavefront walks the payload in lock step: every lane writes the same values
-        RdS r{pay, fr.payload_len, 0, false, smem + 256, 0, 0};
+        RdS r{pay, fr.payload_len, 0, false, smem + 256, 0, 0, STG_BYTES};
         Hdr h;
         h.d0 = h.d1 = 0.0; h.u0 = h.u1 = h.u2 = 0; h.f0 = h.f1 = 0.0f;
         switch (fr.tag) {
@@ -2009,60 +1909,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             const uint64_t cnt = rds_varint(r);
             if (cnt > L) r.bad = true;
             if (!r.bad && cnt <= P.kcap) {
-                // An entry is varint(pos: u16) + f32 + f32 = 9 bytes (pos < 251) or 11 (marker 251 + 2).
-                // 64 entries at a time: lane l assumes 11-byte entries before it, corrected by c = the
-                // number of 9-byte entries among them; c is the exclusive prefix sum of the 9-byte flags
-                // read at the assumed starts, iterated to its fixed point (lane 0 is right at once, lane
-                // k after at most k more rounds; short entries are rare, so one or two rounds usually).
-                // The entries go to the workspace; the whole workgroup applies them below.
-                uint32_t done = 0;
-                while (done < cnt && !r.bad) {
-                    const uint32_t grp = min(64u, (uint32_t)cnt - done);
-                    if (r.pos + 11 * 64 > r.w1 && r.w1 < r.len) rds_fill(r);
-                    uint32_t c = 0, st = 0, first = 251, incl = 0;
-                    for (int it = 0; it < 66; ++it) {
-                        st = r.pos + 11 * tid - 2 * c;
-                        first = (tid < grp && st < r.len) ? r.stg[st - r.w0] : 251u;
-                        const uint32_t sf = (tid < grp && first < 251) ? 1u : 0u;
-                        incl = wave_incl_scan_u32(sf);
-                        const uint32_t cn = incl - sf;
-                        const bool moved = cn != c;
-                        c = cn;
-                        if (__ballot(moved) == 0) break;
-                    }
-                    bool lbad = false;
-                    if (tid < grp) {
-                        uint32_t pos = first, o = st + 1;
-                        if (first == 251) {
-                            if (st + 3 > r.len) lbad = true;
-                            else pos = (uint32_t)r.stg[st + 1 - r.w0] | ((uint32_t)r.stg[st + 2 - r.w0] << 8);
-                            o = st + 3;
-                        } else if (first > 251) {
-                            lbad = true;  // a u16 field: 4- and 8-byte varints cannot occur
-                        }
-                        if (!lbad && o + 8 > r.len) lbad = true;
-                        if (!lbad) {
-                            uint32_t wre = 0, wim = 0;
-                            for (uint32_t b = 0; b < 4; ++b) {
-                                wre |= (uint32_t)r.stg[o + b - r.w0] << (8 * b);
-                                wim |= (uint32_t)r.stg[o + 4 + b - r.w0] << (8 * b);
-                            }
-                            float re = __uint_as_float(wre), im = __uint_as_float(wim);
-                            if (pos >= L) {
-                                lbad = true;
-                            } else {
-                                if (pos > L / 2) { pos = L - pos; im = -im; }  // get_mirrored_freqs (fft.rs:401-422)
-                                if (pos == 0 || 2 * pos == L) im = 0.0f;
-                                ent[done + tid].pos = pos;
-                                ent[done + tid].re = re;
-                                ent[done + tid].im = im;
-                            }
-                        }
-                    }
-                    if (__ballot(lbad)) { r.bad = true; break; }
-                    r.pos += 11 * grp - 2 * (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    done += grp;
-                }
+                rds_fft_entries(r, (uint32_t)cnt, L, ent);  // 64 at a time; the whole workgroup applies them below
                 h.u1 = 1;  // entries wait in the workspace
             } else
             // (a foreign stream with more entries than this library's encoder ever stores: one at a time)

@@ -58,6 +58,16 @@ def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, repor
         errs = oracle_errs or {}
         if any(_near_threshold(e, max_error) for e in errs.values()):
             return "boundary"
+        # Tied norms (documented deviation): the two ladders admitted different bins
+        # of equal norm on the way, so their errors -- and the trip at which they stop -- differ.  Seen as:
+        # over the common length the norms agree in order while the position sets do not.
+        m = min(len(fg), len(fo))
+        if m and set(f[0] for f in fg[:m]) != set(f[0] for f in fo[:m]):
+            sc = max(np.hypot(r, i) for _, r, i in (fo if len(fo) >= len(fg) else fg))
+            ng = [np.hypot(r, i) for _, r, i in fg[:m]]
+            no = [np.hypot(r, i) for _, r, i in fo[:m]]
+            if max(abs(a - b) for a, b in zip(ng, no)) <= FFT_COEF_RTOL * sc:
+                return "tie"
         return "FAIL:fft K gpu=%d oracle=%d" % (len(fg), len(fo))
     scale = max(np.hypot(r, i) for _, r, i in fo) if fo else 1.0
     pos_g = [f[0] for f in fg]

@@ -839,17 +839,18 @@ def _record(tag, n, payload):
     return P.H_varint(41) + P.H_varint(n) + P.H_varint(tag) + P.H_varint(len(payload)) + payload
 
 
-def test_decompress_large_foreign_fft_streams(ctx, A, oracle):
+def test_decompress_foreign_fft_streams(ctx, A, oracle):
     """FFT payloads this library's encoder never writes, decoded like the oracle decodes them: more entries
     than the ladder can store (the decoder's serial parse + dense transform), duplicate positions (later
     entries overwrite), positions above L/2 (mirrored), entries of both widths in one stream."""
     import struct
     rng = np.random.default_rng(77)
-    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500)):
-        L = int(oracle.next_size(n))
+    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500), (256, 40), (1000, 300), (100, 30), (40, 12)):
+        L = int(oracle.next_size(n)) if n >= 128 else n  # fft.rs:432-444: no padding below 128 samples
         pos = rng.integers(0, L, size=cnt)
-        pos[: cnt // 3] = rng.integers(0, 251, size=cnt // 3)          # one-byte positions among the wide ones
-        pos[cnt // 2: cnt // 2 + 20] = pos[:20]                          # duplicates: the later entry wins
+        pos[: cnt // 3] = rng.integers(0, min(251, L), size=cnt // 3)  # one-byte positions among the wide ones
+        ndup = min(20, cnt // 4)
+        pos[cnt // 2: cnt // 2 + ndup] = pos[:ndup]                      # duplicates: the later entry wins
         re = rng.normal(0, 50.0, size=cnt).astype(np.float32)
         im = rng.normal(0, 50.0, size=cnt).astype(np.float32)
         pay = bytes([15]) + P.H_varint(cnt)
@@ -864,11 +865,11 @@ def test_decompress_large_foreign_fft_streams(ctx, A, oracle):
         assert np.max(np.abs(out - ref)) <= tol, (n, cnt, float(np.max(np.abs(out - ref))), tol)
 
 
-def test_decompress_large_mixed_width_varints(ctx, A, oracle):
+def test_decompress_mixed_width_varints(ctx, A, oracle):
     """Polynomial points and Noop values whose zigzag varints mix 1-, 3-, 5- and 9-byte widths at random:
     the 64-at-a-time parse has to settle lane by lane; decode must equal the oracle's bit for bit."""
     rng = np.random.default_rng(78)
-    for n in (4097, 9000, 40000):
+    for n in (4097, 9000, 40000, 64, 300, 2000):
         # Noop: integers around the 251 marker and the 16/32-bit boundaries
         pool = np.array([0, 1, -1, 124, 125, 126, -125, -126, -127, 300, -300, 32767, -32768, 32768, 70000, -70000,
                          2 ** 31 - 1, -2 ** 31, 2 ** 31, 2 ** 40, -2 ** 40], dtype=np.float64)
