@@ -14,7 +14,7 @@
 
 namespace atsc {
 
-template <int W>
+template <int W, int SPL>
 __global__ __launch_bounds__(64 * W) void k_decompress(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
@@ -77,7 +77,12 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
             if (id > 1 || bd > 3 || cnt > n) r.bad = true;
             h.u2 = id;  // PolynomialType decides the interpolation (polynomial.rs:400-403), not the frame tag
             if (!r.bad) {
-                if (wide && (bd == 1 || bd == 2)) {
+                if (bd == 0 || bd == 3) {
+                    // fixed-width points (F64 / U8): skipped here, read by the whole workgroup below
+                    h.f0 = __uint_as_float(r.pos);
+                    r.pos += (uint32_t)cnt * (bd == 0 ? 8u : 1u);
+                    if (r.pos > r.len) r.bad = true;
+                } else if (wide) {
                     rds_varints(r, (uint32_t)cnt, [&](uint32_t i, uint64_t v) {
                         xs[i] = (bd == 2) ? (double)(int16_t)unzig(v) : (double)(int32_t)unzig(v);
                     });
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
                     for (uint32_t i = 0; i < cnt && !r.bad; ++i) xs[i] = rds_value(r, bd);
                 }
             }
+            h.f1 = __uint_as_float(bd);
             h.d0 = __longlong_as_double((long long)rds_le(r, 8));  // min
             h.d1 = __longlong_as_double((long long)rds_le(r, 8));  // max
             h.u0 = (uint32_t)cnt;
@@ -160,7 +166,20 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
             for (uint32_t j = tid; j < n; j += T) out[j] = mx;
             return;
         }
-        const uint32_t step = h.u1, K = h.u0;
+        const uint32_t step = h.u1, K = h.u0, bd = __float_as_uint(h.f1);
+        if (bd == 0 || bd == 3) {
+            const uint8_t *pp = pay + __float_as_uint(h.f0);
+            for (uint32_t k = tid; k < K; k += T) {
+                if (bd == 3) {
+                    xs[k] = (double)pp[k];
+                } else {
+                    uint64_t v = 0;
+                    for (int b = 0; b < 8; ++b) v |= (uint64_t)pp[8 * k + b] << (8 * b);
+                    xs[k] = __longlong_as_double((long long)v);
+                }
+            }
+            __syncthreads();
+        }
         bool ok = step >= 1;
         if (ok) {
             const uint32_t cnt = (n + step - 1) / step;
@@ -223,11 +242,11 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
         const uint32_t magicL = P.magicL;
-        // A thread owns samples tid, tid + T, ... (at most MAXS of them: n <= 576 W); the entries are the
+        // A thread owns samples tid, tid + T, ... (at most SPL of them: n <= L <= 64 W SPL); the entries are the
         // outer loop so that an entry's constants and its twiddle index walk (pos * (j + pre) mod L,
         // advanced by pos * T mod L) are set up once.  Per sample the terms still add up in stream order,
         // and 2 (re wx - im wy) = (2 re) wx - (2 im) wy exactly, so the sums are those of the sample-outer form.
-        constexpr int MAXS = 9;
+        constexpr int MAXS = SPL;
         double acc[MAXS];
 #pragma unroll
         for (int m = 0; m < MAXS; ++m) acc[m] = 0.0;
@@ -286,12 +305,12 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
     }
 }
 
-template <int W>
+template <int W, int SPL>
 static hipError_t launch_d(uint32_t count, uint32_t lds, const DevDFrame *frames,
                            const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                            const uint8_t *body, double *out, int *status, hipStream_t s)
 {
-    auto kern = k_decompress<W>;
+    auto kern = k_decompress<W, SPL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -302,6 +321,7 @@ static hipError_t launch_d(uint32_t count, uint32_t lds, const DevDFrame *frames
     return hipGetLastError();
 }
 
+// frame classes as in the compressor (class_of, atsc_host.cpp): L <= 64 W SPL samples per workgroup
 hipError_t launch_decompress(const DevDFrame *frames, uint64_t n_frames, const uint32_t *ids, int cls,
                              uint32_t count, uint32_t lds, const DevPlan *plans,
                              const float2 *twpool, const uint8_t *body, double *out, int *status,
@@ -310,12 +330,12 @@ hipError_t launch_decompress(const DevDFrame *frames, uint64_t n_frames, const u
     (void)n_frames;
     if (count == 0) return hipSuccess;
     switch (cls) {
-    case 0:
-    case 1:
-    case 2: return launch_d<1>(count, lds, frames, ids, plans, twpool, body, out, status, s);
-    case 3:
-    case 4: return launch_d<4>(count, lds, frames, ids, plans, twpool, body, out, status, s);
-    case 5: return launch_d<16>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 0: return launch_d<1, 2>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 1: return launch_d<1, 5>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 2: return launch_d<1, 9>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 3: return launch_d<4, 5>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 4: return launch_d<4, 9>(count, lds, frames, ids, plans, twpool, body, out, status, s);
+    case 5: return launch_d<16, 5>(count, lds, frames, ids, plans, twpool, body, out, status, s);
     default: return hipErrorInvalidValue;
     }
 }
