@@ -12,6 +12,7 @@
 #include <memory>
 #include <string>
 #include <tuple>
+#include <thread>
 #include <vector>
 
 #include "../../include/atsc_hip.h"
@@ -244,18 +245,41 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
     if (compressor < 0 || compressor > 6 || sample_level < 0 || sample_level > 6) return ATSC_E_INVALID;
     // OptimizerPlan::plan drops NaN and infinite samples (optimizer/mod.rs:47-49); the copy is only
     // made when there is something to drop
+    // Long inputs are scanned by a helper thread while this one already sends the samples to the GPU and
+    // compresses them as they are (the scan reads 8 B per sample at host-memory speed, about what the
+    // pageable copy takes); if the scan does find something to drop, that result is discarded and the
+    // cleaned copy goes through.
+    auto has_nonfinite = [](const double *p, uint64_t cnt) {
+        for (uint64_t b = 0; b < cnt; b += 4096) {
+            const uint64_t e = std::min<uint64_t>(b + 4096, cnt);
+            uint64_t bad = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t bits;
+                memcpy(&bits, p + i, 8);
+                bad |= ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull) ? 1u : 0u;
+            }
+            if (bad) return true;
+        }
+        return false;
+    };
     bool dirty = false;
-    for (uint64_t i = 0; i < n && !dirty; ++i) dirty = !std::isfinite(data[i]);
+    std::thread scanner;
+    const bool overlap = n >= (1u << 20);
+    if (overlap) scanner = std::thread([&] { dirty = has_nonfinite(data, n); });
+    else dirty = has_nonfinite(data, n);
     std::vector<double> clean;
     const double *src = data;
     uint64_t cn = n;
-    if (dirty) {
+    bool use_clean = !overlap && dirty;  // (with a scanner running, `dirty` is its to write until the join)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    if (use_clean) {
         clean.resize(n);
         cn = atsc_clean_data(data, n, clean.data());
         src = clean.data();
     }
     const uint64_t nch = atsc_chunk_sizes(cn, nullptr, 0);
     if (nch == 0) {  // an empty stream: header + count 0 (data.rs:79-85)
+        if (scanner.joinable()) scanner.join();
         uint8_t *buf = (uint8_t *)malloc(18);
         if (!buf) return ATSC_E_NOMEM;
         *len = atsc_bro_prefix(0, buf);
@@ -275,16 +299,26 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
                        compressor == ATSC_AUTO;                            // main.rs:150-162
     const float max_error = lossy ? (float)error_pct / 100.0f : 0.0f;      // main.rs:157
     uint8_t *buf = (uint8_t *)malloc(18 + cap);  // worst case; only the bytes produced are touched
-    if (!buf) return ATSC_E_NOMEM;
+    if (!buf) { if (scanner.joinable()) scanner.join(); return ATSC_E_NOMEM; }
     const uint64_t pre = atsc_bro_prefix(nch, buf);
     uint64_t blen = 0;
     int rc = atsc_compress_frames(ctx, src, off.data(), nch, compressor, lossy ? 1 : 0, max_error,
                                   lossy ? sample_level : 0, buf + pre, cap, &blen, nullptr, nullptr, nullptr);
+    if (scanner.joinable()) {
+        scanner.join();
+        if (dirty) {  // compressed with samples the reference drops: again, from the cleaned copy
+            free(buf);
+            use_clean = true;
+            continue;
+        }
+    }
     if (rc) { free(buf); return rc; }
     uint8_t *fit = (uint8_t *)realloc(buf, pre + blen);
     *bro = fit ? fit : buf;
     *len = pre + blen;
     return ATSC_OK;
+    }
+    return ATSC_E_INVALID;  // not reached: the second attempt has no scanner left to send it round again
 }
 
 extern "C" int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, double **out, uint64_t *n)

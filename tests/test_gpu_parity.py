@@ -886,3 +886,27 @@ def test_decompress_mixed_width_varints(ctx, A, oracle):
             ref = np.array(oracle.decompress(A.POLYNOMIAL, po, n))
             out = ctx.decompress_host(_record(A.POLYNOMIAL, n, po))
             assert np.array_equal(out, ref), ("poly", n, lim)
+
+
+def test_compress_data_long_input_with_nonfinite_samples(ctx, A):
+    """OptimizerPlan::plan drops NaN / infinite samples (optimizer/mod.rs:47-49).  On a long input the scan
+    runs beside the GPU work and a hit sends the cleaned copy through again: the stream has to equal the one
+    made from the cleaned series, and a clean long input has to equal itself compressed in two halves' framing
+    (same chunker) -- i.e. the speculative first pass leaves nothing behind."""
+    x = H.synth_series(31, 1500000)
+    clean_bro = A.compress_data(ctx, x, A.AUTO, 5)
+    y = x.copy()
+    ys = []
+    cut = [7, 131072, 700001, 1499999]
+    prev = 0
+    for k, c in enumerate(cut):
+        ys.append(y[prev:c])
+        ys.append(np.array([np.nan, np.inf, -np.inf][k % 3: k % 3 + 1]))
+        prev = c
+    ys.append(y[prev:])
+    dirty = np.concatenate(ys)
+    assert len(dirty) == len(x) + len(cut)
+    assert A.compress_data(ctx, dirty, A.AUTO, 5) == clean_bro
+    assert A.compress_data(ctx, x, A.AUTO, 5) == clean_bro
+    out = A.decompress_data(ctx, clean_bro)
+    assert len(out) == len(x)
