@@ -1165,32 +1165,55 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     }
                     __syncthreads();
                     double s = 0.0;
-                    for (uint32_t i = tid; i < n; i += T) {
-                        double sv;
-                        if (i == n - 1) {
-                            sv = xs[n - 1];
-                        } else {
-                            uint32_t sg = __umulhi(i, magic);
-                            if (sg > K - 2) sg = K - 2;
-                            const uint32_t t0i = sg * step;
-                            const bool last = (sg == K - 2);
-                            const uint32_t t1i = last ? (n - 1) : t0i + step;
-                            const double v0 = xs[t0i], v1 = xs[t1i];
-                            if (sg > 0 && !last) {
-                                const double2 t = mm[sg];
-                                const double4 h = hbt[i - t0i];
-                                sv = v0 * h.x + t.x * h.y + v1 * h.z + t.y * h.w;
-                            } else {
-                                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
-                                                            last ? ryL : ry);
-                                sv = v0 * (1.0 - nt) + v1 * nt;
+                    // four samples of a thread at a time: their loads (sample, two knots, tangents) are all
+                    // issued before the first value is used -- one sample after the other the loop waits
+                    // out a memory round trip per sample
+                    for (uint32_t i0 = tid; i0 < n; i0 += 4 * T) {
+                        double g[4], v0[4], v1[4];
+                        double2 tg[4];
+                        uint32_t sgs[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t i = i0 + u * T;
+                            g[u] = v0[u] = v1[u] = 0.0;
+                            tg[u] = make_double2(0.0, 0.0);
+                            sgs[u] = 0;
+                            if (i < n) {
+                                uint32_t sg = __umulhi(i, magic);
+                                if (sg > K - 2) sg = K - 2;
+                                const uint32_t t0i = sg * step;
+                                const bool last = (sg == K - 2);
+                                sgs[u] = sg;
+                                g[u] = xs[i];
+                                v0[u] = xs[t0i];
+                                v1[u] = xs[last ? (n - 1) : t0i + step];
+                                if (sg > 0 && !last) tg[u] = mm[sg];
                             }
                         }
-                        double o = div1e5(round(sv * 100000.0));
-                        if (o < smin) o = smin;
-                        else if (o > smax) o = smax;
-                        const double g = xs[i];
-                        s += fabs((o - g) / g);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t i = i0 + u * T;
+                            if (i >= n) continue;
+                            double sv;
+                            if (i == n - 1) {
+                                sv = g[u];
+                            } else {
+                                const uint32_t sg = sgs[u], t0i = sg * step;
+                                const bool last = (sg == K - 2);
+                                if (sg > 0 && !last) {
+                                    const double4 h = hbt[i - t0i];
+                                    sv = v0[u] * h.x + tg[u].x * h.y + v1[u] * h.z + tg[u].y * h.w;
+                                } else {
+                                    const double nt = div_small((double)(i - t0i), last ? gapLd : stepd,
+                                                                last ? ryL : ry);
+                                    sv = v0[u] * (1.0 - nt) + v1[u] * nt;
+                                }
+                            }
+                            double o = div1e5(round(sv * 100000.0));
+                            if (o < smin) o = smin;
+                            else if (o > smax) o = smax;
+                            s += fabs((o - g[u]) / g[u]);
+                        }
                     }
                     s = block_sum_f64<W>(s, red, parity);
                     cur = s / (double)n;
