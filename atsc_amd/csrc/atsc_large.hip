@@ -392,10 +392,11 @@ struct SpEnt {
 };
 
 // entry(i, p, x): bin position p (<= L/2) and value x of list entry i, false if the entry is void;
-// ev(j, re): sample j of the padded signal before the division by L.  zl: 2 K entries of scratch.
-template <class EntryFn, class EvalFn>
+// gload(j): what ev wants to know about sample j of the padded signal (loaded four samples ahead of the
+// arithmetic); ev(j, re, g): sample j before the division by L.  zl: 2 K entries of scratch.
+template <class EntryFn, class LoadFn, class EvalFn>
 DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl, const float2 *tw,
-                         unsigned char *lds, uint32_t *wsum, EvalFn ev, uint32_t dbg = 0)
+                         unsigned char *lds, uint32_t *wsum, LoadFn gload, EvalFn ev, uint32_t dbg = 0)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t Mf = P.sp_mf, Md = P.sp_md, M = P.M, L = P.L, sc = P.sc;
@@ -508,16 +509,37 @@ DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl,
         __syncthreads();
         const float2 *R = (dbg & 2) ? T : lds_fft<true, SPB>(T, U, wf, Mf, nseq, SPB, 1);
         if (dbg & 4) continue;
-        for (uint32_t w = tid; w < Mf * SPB; w += LT) {
-            const uint32_t c = w & (SPB - 1), ja = w / SPB;
-            if (c >= nseq) continue;
-            const float2 f = R[ja * SPB + c];
-            const uint32_t j = Md * ja + jb0 + c;
-            if (half) {  // idft_L = 2 * idft_M: even sample -> re, odd sample -> -im
-                ev(2 * j, 2.0f * f.x);
-                ev(2 * j + 1, -2.0f * f.y);
-            } else {
-                ev(j, f.x);
+        if ((tid & (SPB - 1)) < nseq) {
+            const uint32_t npt = Mf * SPB, jc = jb0 + (tid & (SPB - 1));
+            for (uint32_t w0 = tid; w0 < npt; w0 += 4 * LT) {
+                decltype(gload(0u)) g0[4], g1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t w = w0 + u * LT;
+                    if (w < npt) {
+                        const uint32_t j = Md * (w / SPB) + jc;
+                        if (half) {
+                            g0[u] = gload(2 * j);
+                            g1[u] = gload(2 * j + 1);
+                        } else {
+                            g0[u] = gload(j);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t w = w0 + u * LT;
+                    if (w < npt) {
+                        const float2 f = R[w];
+                        const uint32_t j = Md * (w / SPB) + jc;
+                        if (half) {  // idft_L = 2 * idft_M: even sample -> re, odd sample -> -im
+                            ev(2 * j, 2.0f * f.x, g0[u]);
+                            ev(2 * j + 1, -2.0f * f.y, g1[u]);
+                        } else {
+                            ev(j, f.x, g0[u]);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1534,12 +1556,12 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                             return true;
                         },
                         (SpEnt *)work, tw, (unsigned char *)keys, wsum,
-                        [&](uint32_t j, float re) {
+                        [&](uint32_t j) -> double { return gpad(j); },
+                        [&](uint32_t, float re, double g) {
                             const double v = (double)(re / Lf);
                             double o = div1e5(round(v * 100000.0));
                             if (o > mxd) o = mxd;
                             if (o < mnd) o = mnd;
-                            const double g = gpad(j);
                             s += fabs(o - g) * recip_abs(g);  // the product form, as in k_compress
                         },
                         prm.debug_stop >= 16 ? (uint32_t)prm.debug_stop - 16u : 0u);
@@ -2142,7 +2164,8 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
                         return own[p] == i + 1;
                     },
                     (SpEnt *)Cb, tw, smem + 256, wsum,
-                    [&](uint32_t j, float re) {
+                    [](uint32_t) -> int { return 0; },
+                    [&](uint32_t j, float re, int) {
                         const uint32_t i = j - pre;
                         if (i < n) {
                             const float v = re / Lf;
