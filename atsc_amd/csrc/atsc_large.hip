@@ -996,12 +996,22 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             uint32_t *mine = (uint32_t *)tab + wv * min(seg, 8192u);  // <= 4 n + 4 KB of the (idle) hash-table region
             const uint64_t lt = (1ull << lane) - 1ull;
             uint32_t cnt = 0;
-            for (uint32_t j0 = s0; j0 < s1; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool fl = j < s1 && (j + 1 >= n || xs[j + 1] != xs[j]);
-                const uint64_t m = __ballot(fl);
-                if (fl) mine[cnt + (uint32_t)__popcll(m & lt)] = j;
-                cnt += (uint32_t)__popcll(m);
+            for (uint32_t jb = s0; jb < s1; jb += 256) {  // four 64-sample windows' loads in flight
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t j = jb + 64 * u + lane;
+                    a[u] = j < s1 ? xs[j] : 0.0;
+                    b[u] = (j < s1 && j + 1 < n) ? xs[j + 1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t j = jb + 64 * u + lane;
+                    const bool fl = j < s1 && (j + 1 >= n || b[u] != a[u]);
+                    const uint64_t m = __ballot(fl);
+                    if (fl) mine[cnt + (uint32_t)__popcll(m & lt)] = j;
+                    cnt += (uint32_t)__popcll(m);
+                }
             }
             if (lane == 0) wsum[wv] = cnt;
             __syncthreads();
@@ -1365,7 +1375,14 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 for (uint32_t i = tid; i < 2048; i += T) h2[i] = 0;
                 if (tid == 0) { bc[2] = 0; bc[3] = 0; bc[4] = 0xFFFFFFFFu; }
                 __syncthreads();
-                for (uint32_t k = tid; k < bins; k += T) atomicAdd(&h2[2047u - (nbits[k] >> 20)], 1u);
+                for (uint32_t k0 = tid; k0 < bins; k0 += 4 * T) {  // four loads in flight per thread
+                    uint32_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (k0 + u * T < bins) ? nbits[k0 + u * T] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k0 + u * T < bins) atomicAdd(&h2[2047u - (v[u] >> 20)], 1u);
+                }
                 __syncthreads();
                 {
                     const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
@@ -1382,9 +1399,16 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 if (bc[4] != 0xFFFFFFFFu && n_above <= CAND0 && n_cand <= LKEYS_MAX - CAND0) {
                     const uint32_t lane = tid & 63u;
                     const uint64_t lt = (1ull << lane) - 1ull;
-                    for (uint32_t k0 = 0; k0 < bins; k0 += T) {
+                    for (uint32_t kb = 0; kb < bins; kb += 4 * T) {
+                    uint32_t vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) vv[u] = (kb + u * T + tid < bins) ? nbits[kb + u * T + tid] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t k0 = kb + u * T;
+                        if (k0 >= bins) break;
                         const uint32_t k = k0 + tid;
-                        const uint32_t v = k < bins ? nbits[k] : 0u;
+                        const uint32_t v = vv[u];
                         const uint32_t d = v >> 20;
                         const bool ab = k < bins && d > dstar, cd = k < bins && d == dstar;
                         const uint64_t key = ((uint64_t)(~v) << 32) | (uint64_t)k;
@@ -1401,6 +1425,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                             if (cd) keys[CAND0 + base + (uint32_t)__popcll(mc & lt)] = key;
                         }
+                    }
                     }
                     __syncthreads();
                     uint32_t pa = 1, pc = 1;
