@@ -479,7 +479,32 @@ DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl,
     }
     __syncthreads();
     for (uint32_t ka = tid; ka < Mf; ka += LT) {
-        const uint32_t b = beg[ka], e = end[ka];
+        const uint32_t b = beg[ka], e = end[ka], c = e - b;
+        if (c <= 1) continue;
+        if (c <= 8) {
+            // the usual bucket: all of it into registers at once (one memory round trip instead of a chain
+            // of dependent ones), a 19-exchange network, back
+            SpEnt v[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
+                v[i].key = 0xFFFFFFFFu;
+                v[i].re = v[i].im = 0.0f;
+                if (i < c) v[i] = zl[b + i];
+            }
+            auto cx = [&](SpEnt &x, SpEnt &y) {
+                if (x.key > y.key) { const SpEnt t = x; x = y; y = t; }
+            };
+            cx(v[0], v[1]); cx(v[2], v[3]); cx(v[4], v[5]); cx(v[6], v[7]);
+            cx(v[0], v[2]); cx(v[1], v[3]); cx(v[4], v[6]); cx(v[5], v[7]);
+            cx(v[1], v[2]); cx(v[5], v[6]);
+            cx(v[0], v[4]); cx(v[1], v[5]); cx(v[2], v[6]); cx(v[3], v[7]);
+            cx(v[2], v[4]); cx(v[3], v[5]);
+            cx(v[1], v[2]); cx(v[3], v[4]); cx(v[5], v[6]);
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i)
+                if (i < c) zl[b + i] = v[i];
+            continue;
+        }
         for (uint32_t a = b + 1; a < e; ++a) {
             const SpEnt t = zl[a];
             uint32_t j = a;
