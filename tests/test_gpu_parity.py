@@ -910,3 +910,45 @@ def test_compress_data_long_input_with_nonfinite_samples(ctx, A):
     assert A.compress_data(ctx, x, A.AUTO, 5) == clean_bro
     out = A.decompress_data(ctx, clean_bro)
     assert len(out) == len(x)
+
+
+def test_large_frames_sparse_and_dense_inverse_agree(ctx, A, oracle, monkeypatch):
+    """The large tier's ladder reconstructs from the sparse bin list (sparse_inverse); ATSC_LARGE_DENSE keeps
+    the dense transforms through the workspace.  Same forward transform, so the stored coefficients are the
+    same numbers: the two must pick the same codecs and write the same bytes unless a frame sits on a decision
+    threshold (counted, rare), and both decoders must reproduce the oracle's decode of the sparse stream."""
+    sizes = [4097, 6561, 8192, 20000, 65536, 131072]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in ((0, 1) if n > 50000 else (0, 1, 2, 3)):
+            xs.append(H.synth_series(1200 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    nf = len(off) - 1
+    for comp, me in ((A.AUTO, ME5), (A.FFT, ME1)):
+        monkeypatch.delenv("ATSC_LARGE_DENSE", raising=False)
+        rec_s, off_s, ch_s, err_s = ctx.compress_host(x, off, comp, True, me, 0)
+        out_s = ctx.decompress_host(rec_s)
+        monkeypatch.setenv("ATSC_LARGE_DENSE", "1")
+        rec_d, off_d, ch_d, err_d = ctx.compress_host(x, off, comp, True, me, 0)
+        out_d = ctx.decompress_host(rec_s)
+        monkeypatch.delenv("ATSC_LARGE_DENSE", raising=False)
+        assert np.array_equal(ch_s, ch_d)
+        fs = H.parse_bro_body(rec_s, with_count=False)
+        fd = H.parse_bro_body(rec_d, with_count=False)
+        differ = sum(1 for a, b in zip(fs, fd) if a != b)
+        assert differ <= 1, (comp, differ)
+        tol = P.FFT_ERR_ATOL + P.FFT_ERR_RTOL * np.abs(err_d) + np.array(
+            [P.fft_err_noise(x[int(off[i]):int(off[i + 1])]) for i in range(nf)])
+        assert np.all(np.abs(err_s - err_d) <= tol) or differ
+        ref = np.array(oracle.decompress_data(A.bro_prefix(nf) + rec_s))
+        for i in range(nf):
+            seg = slice(int(off[i]), int(off[i + 1]))
+            n = seg.stop - seg.start
+            if ch_s[i] == oracle.FFT:
+                scale = max(np.max(np.abs(ref[seg])), 1e-30)
+                t = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5
+                assert np.max(np.abs(out_s[seg] - ref[seg])) <= t and np.max(np.abs(out_d[seg] - ref[seg])) <= t, (comp, i)
+            else:
+                assert np.array_equal(out_s[seg], ref[seg]) and np.array_equal(out_d[seg], ref[seg]), (comp, i)
