@@ -394,17 +394,35 @@ struct SpEnt {
 // entry(i, p, x): bin position p (<= L/2) and value x of list entry i, false if the entry is void;
 // gload(j): what ev wants to know about sample j of the padded signal (loaded four samples ahead of the
 // arithmetic); ev(j, re, g): sample j before the division by L.  zl: 2 K entries of scratch.
-template <class EntryFn, class LoadFn, class EvalFn>
-DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl, const float2 *tw,
-                         unsigned char *lds, uint32_t *wsum, LoadFn gload, EvalFn ev, uint32_t dbg = 0)
+// LDS carve of the sparse inverse: tile buffers T, U (SPB x Mf points each), W_Mf and W_Md tables, bucket bounds
+struct SpLds {
+    float2 *T, *U, *wf, *wd;
+    uint32_t *beg, *end;
+};
+DEVI SpLds sp_lds(const DevPlan &P, unsigned char *lds)
+{
+    SpLds s;
+    s.T = (float2 *)lds;
+    s.U = s.T + SPB * P.sp_mf;
+    s.wf = s.U + SPB * P.sp_mf;
+    s.wd = s.wf + P.sp_mf;
+    s.beg = (uint32_t *)(s.wd + P.sp_md);
+    s.end = s.beg + P.sp_mf + 4;
+    return s;
+}
+
+// first half: the tables and the list bucketed by ka in zl[], bucket bounds in LDS (beg / end)
+template <class EntryFn>
+DEVI void sparse_bucket(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl, const float2 *tw,
+                        unsigned char *lds, uint32_t *wsum)
 {
     const uint32_t tid = threadIdx.x;
-    const uint32_t Mf = P.sp_mf, Md = P.sp_md, M = P.M, L = P.L, sc = P.sc;
+    const uint32_t Mf = P.sp_mf, Md = P.sp_md, M = P.M, L = P.L;
     const bool half = P.half != 0;
-    float2 *T = (float2 *)lds, *U = T + SPB * Mf, *wf = U + SPB * Mf, *wd = wf + Mf;
-    uint32_t *beg = (uint32_t *)(wd + Md), *end = beg + Mf + 4;
+    const SpLds sl = sp_lds(P, lds);
+    float2 *wf = sl.wf, *wd = sl.wd;
+    uint32_t *beg = sl.beg, *end = sl.end;
     const uint32_t mg_mf = (uint32_t)(0x100000000ull / Mf) + 1u;
-    const uint32_t mg_md = Md >= 2 ? (uint32_t)(0x100000000ull / Md) + 1u : 0u;
 
     for (uint32_t e = tid; e < Mf; e += LT) {
         wf[e] = tw[e * (L / Mf)];
@@ -514,7 +532,22 @@ DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl,
     }
     __syncthreads();
 
-    for (uint32_t jb0 = 0; jb0 < Md; jb0 += SPB) {
+}
+
+// second half: output columns jb0 .. jb0 + SPB - 1 (needs the tables and bucket bounds in LDS, the list in zl[])
+template <class LoadFn, class EvalFn>
+DEVI void sparse_tile(const DevPlan &P, uint32_t jb0, const SpEnt *zl, const float2 *tw, unsigned char *lds,
+                      LoadFn gload, EvalFn ev, uint32_t dbg = 0)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Mf = P.sp_mf, Md = P.sp_md, sc = P.sc;
+    const bool half = P.half != 0;
+    const SpLds sl = sp_lds(P, lds);
+    float2 *T = sl.T, *U = sl.U;
+    const float2 *wf = sl.wf, *wd = sl.wd;
+    const uint32_t *beg = sl.beg, *end = sl.end;
+    const uint32_t mg_md = Md >= 2 ? (uint32_t)(0x100000000ull / Md) + 1u : 0u;
+    {
         const uint32_t nseq = min(SPB, Md - jb0);
         for (uint32_t w = tid; w < Mf * SPB; w += LT) {
             const uint32_t c = w & (SPB - 1), ka = w / SPB;
@@ -533,7 +566,7 @@ DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl,
         }
         __syncthreads();
         const float2 *R = (dbg & 2) ? T : lds_fft<true, SPB>(T, U, wf, Mf, nseq, SPB, 1);
-        if (dbg & 4) continue;
+        if (dbg & 4) { __syncthreads(); return; }
         if ((tid & (SPB - 1)) < nseq) {
             const uint32_t npt = Mf * SPB, jc = jb0 + (tid & (SPB - 1));
             for (uint32_t w0 = tid; w0 < npt; w0 += 4 * LT) {
@@ -569,6 +602,14 @@ DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl,
         }
         __syncthreads();
     }
+}
+
+template <class EntryFn, class LoadFn, class EvalFn>
+DEVI void sparse_inverse(const DevPlan &P, uint32_t K, EntryFn entry, SpEnt *zl, const float2 *tw,
+                         unsigned char *lds, uint32_t *wsum, LoadFn gload, EvalFn ev, uint32_t dbg = 0)
+{
+    sparse_bucket(P, K, entry, zl, tw, lds, wsum);
+    for (uint32_t jb0 = 0; jb0 < P.sp_md; jb0 += SPB) sparse_tile(P, jb0, zl, tw, lds, gload, ev, dbg);
 }
 
 // sort of u64 run records rec = (start << 32 | end) by (bits of xs[end], start)
