@@ -31,7 +31,8 @@ uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre = nullptr);
+                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre = nullptr,
+                                   uint32_t sp_tiles = 0);
 hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, const uint32_t *cost, uint8_t *bkt,
                                 uint32_t *hist_cursor, const uint32_t *class_first,
                                 const uint32_t *class_count, int n_classes, hipStream_t s);
@@ -154,6 +155,7 @@ struct atsc_dplan {
     uint32_t ws_slots = 0;
     bool large_tiled = false;
     LargePre large_pre{0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
+    uint32_t large_sp_tiles = 0;        // tiles per frame of the sparse inverse's (tile, frame) grid (0: off)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1274,6 +1276,10 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         std::sort(lp.begin(), lp.end());
         lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
         p->large_pre = large_pre_extents(p->tabs.plans, lp);
+        // grid extent of k_decompress_large_tiles: the most tiles (8 output columns each) a large frame has
+        for (uint32_t pi : lp)
+            if (p->tabs.plans[pi].sp_mf) p->large_sp_tiles = std::max(p->large_sp_tiles, (p->tabs.plans[pi].sp_md + 7) / 8);
+        if (getenv("ATSC_LARGE_DECODE_ONE_KERNEL")) p->large_sp_tiles = 0;
     }
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_dplan_destroy(p); return rc; }
@@ -1310,7 +1316,7 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
                                         dp->tabs.d_plans, dp->tabs.d_tw, d_body, d_out, dp->d_status,
                                         dp->d_ws, dp->ws_stride, dp->ws_slots, dp->large_tiled ? 1 : 0,
                                         large_sparse() ? 1 : 0, s,
-                                        dp->large_pre.tiles1 ? &dp->large_pre : nullptr);
+                                        dp->large_pre.tiles1 ? &dp->large_pre : nullptr, dp->large_sp_tiles);
         else
             e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
                                   dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,

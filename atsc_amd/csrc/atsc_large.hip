@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
     const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
-    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse)
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse, int sp_split)
 {
     constexpr int T = LT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1987,7 +1987,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
         }
         return;
     }
-    if (PH == 1 && tid == 0) pend->pending = 0;
+    if ((PH == 1 || (PH == 0 && sp_split)) && tid == 0) pend->pending = 0;
 
     // fixed-width point arrays (U8 / F64) are read in parallel after the header; the spectrum must be
     // empty before lane 0 starts filling it
@@ -2243,6 +2243,28 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
             __syncthreads();
             for (uint32_t i = tid; i < cnt; i += T) atomicMax(&own[ent[i].pos], i + 1);
             __syncthreads();
+            if (PH == 0 && sparse && P.sp_mf && sp_split) {
+                // The list is bucketed here; the tiles -- independent of each other from here on -- go to
+                // k_decompress_large_tiles, a (tile, frame) grid over the whole GPU: a batch of few frames
+                // is bound by one workgroup's 9+ tiles in a row otherwise.
+                sparse_bucket(
+                    P, cnt,
+                    [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+                        const Sel e = ent[i];
+                        p = e.pos;
+                        x = make_float2(e.re, e.im);
+                        return own[p] == i + 1;
+                    },
+                    (SpEnt *)Cb, tw, smem + 256, wsum);
+                const SpLds sl = sp_lds(P, smem + 256);
+                uint32_t *gb = (uint32_t *)(ws + lay.o_nb);  // 2 Mf words of the (idle) norm-bit region
+                for (uint32_t e = tid; e < P.sp_mf; e += T) {
+                    gb[e] = sl.beg[e];
+                    gb[P.sp_mf + e] = sl.end[e];
+                }
+                if (tid == 0) { pend->mxf = mxf; pend->mnf = mnf; pend->pending = 2; }
+                return;
+            }
             if (PH == 0 && sparse && P.sp_mf) {
                 const double mxd = (double)mxf, mnd = (double)mnf;
                 const float Lf = (float)L;
@@ -2333,10 +2355,56 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     }
 }
 
+// One tile (SPB output columns) of one FFT frame whose list k_decompress_large<0> bucketed (DecPending::pending == 2)
+__global__ __launch_bounds__(LT) void k_decompress_large_tiles(
+    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, double *__restrict__ outp,
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const DevDFrame fr = frames[ids[blockIdx.y]];
+    if (fr.tag != ATSC_FFT) return;
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t jb0 = blockIdx.x * SPB;
+    if (!P.sp_mf || jb0 >= P.sp_md) return;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    const LargeWs lay = large_ws_layout(fr.n, P.L, P.kcap);
+    const DecPending *pend = (const DecPending *)(ws + lay.o_cnt);
+    if (pend->pending != 2) return;
+    const uint32_t n = fr.n, L = P.L, pre = P.pre, Mf = P.sp_mf, Md = P.sp_md;
+    const float2 *tw = twpool + P.tw_off;
+    const SpLds sl = sp_lds(P, smem);
+    const uint32_t *gb = (const uint32_t *)(ws + lay.o_nb);
+    for (uint32_t e = tid; e < Mf; e += LT) {
+        sl.wf[e] = tw[e * (L / Mf)];
+        sl.beg[e] = gb[e];
+        sl.end[e] = gb[Mf + e];
+    }
+    for (uint32_t e = tid; e < Md; e += LT) sl.wd[e] = tw[e * (L / Md)];
+    __syncthreads();
+    double *out = outp + fr.out_off;
+    const double mxd = (double)pend->mxf, mnd = (double)pend->mnf;
+    const float Lf = (float)L;
+    sparse_tile(
+        P, jb0, (const SpEnt *)(ws + lay.o_c), tw, smem, [](uint32_t) -> int { return 0; },
+        [&](uint32_t j, float re, int) {
+            const uint32_t i = j - pre;
+            if (i < n) {
+                const float v = re / Lf;
+                double o = round((double)v * 100000.0) / 100000.0;
+                if (o > mxd) o = mxd;
+                if (o < mnd) o = mnd;
+                out[i] = o;
+            }
+        });
+}
+
 hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
                                    double *out, int *status, unsigned char *ws, uint64_t ws_stride,
-                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre)
+                                   uint32_t ws_slots, int tiled, int sparse, hipStream_t s, const LargePre *pre,
+                                   uint32_t sp_tiles)
 {
     // 256 B of header scratch + the tile buffers of the LDS-tiled inverse transform
     const uint32_t lds = 256 + max((2 * F4_TILE + 2 * F4_MAX) * (uint32_t)sizeof(float2), SP_LDS_BYTES);
@@ -2344,6 +2412,11 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
     // decoder needs no pass over the workspace at all
     const bool split = pre && pre->tiles1 && !sparse;
     hipError_t e;
+    if (sparse && sp_tiles) {
+        e = hipFuncSetAttribute((const void *)k_decompress_large_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SP_LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
     uint32_t lds1 = 0, lds2 = 0;
     if (split) {
         lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
@@ -2362,16 +2435,20 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             // parse + every codec but the FFT transform; the transform of all pending frames over the whole
             // GPU; scale / round / clamp
             hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256 + STG_BYTES, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse);
+                               body, out, status, ws, ws_stride, tiled, sparse, 0);
             hipLaunchKernelGGL((k_large_pre1<DevDFrame, true>), dim3(pre->tiles1, nb), dim3(PT), lds1, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL((k_large_pre2<DevDFrame, true>), dim3(pre->tiles2, nb), dim3(PT), lds2, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL(k_decompress_large<2>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse);
+                               body, out, status, ws, ws_stride, tiled, sparse, 0);
         } else {
+            const int sp_split = (sparse && sp_tiles) ? 1 : 0;
             hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse);
+                               body, out, status, ws, ws_stride, tiled, sparse, sp_split);
+            if (sp_split)
+                hipLaunchKernelGGL(k_decompress_large_tiles, dim3(sp_tiles, nb), dim3(LT), SP_LDS_BYTES, s, frames,
+                                   ids + b0, plans, twpool, out, ws, ws_stride);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
