@@ -126,7 +126,10 @@ struct KParams {
 struct LargePre {
     uint32_t tiles1, tiles2, chunks;  // max over frame lengths: column tiles, row tiles, 256-bin chunks
     uint32_t m1_max, m2_max;          // longest sub-transforms: size the tile buffers in LDS
+    uint32_t sp_tiles;                // most tiles (8 output columns each) the sparse inverse of a frame has
 };
+constexpr uint32_t LARGE_SPLIT_MAX = 128;  // large frames per launch up to which the first FFT trip's tiles
+                                           // run as a (tile, frame) grid (launch_compress_large)
 
 // Uniform launch: every frame of the class has the same length and frame f of the class sits at
 // sample_off0 + f*n with its slot at slot_off0 + f*slot_stride; the frame descriptor is then

@@ -331,7 +331,7 @@ DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw,
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -353,6 +353,7 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_rph = o; o += lw_align(4ull * (n + 8));
     w.o_spos = o; o += lw_align(4ull * (16384 + 8));  // admission order (bin positions) once sorted: frees the LDS
     w.o_cnt = o; o += lw_align(16);                   // pre-pass: number of ZERO bins (rare: few atomics)
+    w.o_front = o; o += lw_align(256);                // k_compress_large<1> -> <2>: TripState
     w.bytes = o;
     return w;
 }
@@ -854,6 +855,25 @@ __global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ s
 // --------------------------------------------------------------------------------------------
 constexpr uint32_t LKEYS_MAX = 16384;  // LDS sort capacity (kcap of a 131072-sample frame is 13100)
 
+// What the first part of a split run hands to the second (PART 1 -> k_large_trip_tiles -> PART 2)
+struct TripState {
+    double smin, smax, poly_err, pcur;
+    atsc_frame_diag dg;
+    uint32_t finished;  // 1: PART 1 handled the whole frame (no first FFT trip to farm out)
+    uint32_t bitdepth, rle_size, rle_R, rle_D, rle_ib, rle_lb, best_size;
+    uint32_t poly_step, poly_K, poly_size, poly_trips, pjump;
+    uint32_t Z, nkeys, used;
+    int32_t mode, best_owner;
+    uint32_t flags;     // 1 rle_sorted, 2 rle_pending, 4 poly_done, 8 poly_pruned, 16 poly_active
+};
+constexpr uint32_t TRIP_BOUNDS_OFF = 0, TRIP_PARTIAL_OFF = 8192;  // inside buffer C: bucket bounds, tile sums
+
+// PART 0: the whole per-frame compressor.  PART 1 / PART 2: the same code cut inside the first FFT trip,
+// after the admitted bins are bucketed: for a batch with fewer large frames than CUs the trip's tiles --
+// independent of each other from there on -- run as a (tile, frame) grid over the whole GPU
+// (k_large_trip_tiles) instead of one after the other on the frame's CU; PART 2 adds the tile sums up and
+// goes on with the ladder.  A frame whose PART 1 never reaches that point is finished there.
+template <int PART>
 __global__ __launch_bounds__(LT) void k_compress_large(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
@@ -919,7 +939,15 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         return m == ATSC_AUTO || m == ATSC_RLE;
     }();
     uint32_t st_runs = 0, st_ibytes = 0;
-    {
+    TripState *fst = (TripState *)(ws + lay.o_front);
+    if (PART == 1 && tid == 0) fst->finished = 1;  // until the cut says otherwise
+    if (PART == 2) {
+        if (fst->finished) return;
+        smin = fst->smin;
+        smax = fst->smax;
+        bitdepth = fst->bitdepth;
+        mode = fst->mode;
+    } else {
         const double x0 = xs[0];
         double mn = x0, mx = x0;
         uint32_t fr_any = 0;
@@ -991,7 +1019,9 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     dg.fft_trips = dg.fft_k = dg.poly_trips = dg.poly_step = 0;
     dg.poly_points = 0;
     dg.fft_err = dg.poly_err = 0.0;
+    if (PART == 2) dg = fst->dg;
 
+    if (PART != 2) {
     if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && !prm.trial && smin == smax)) {
         if (tid == 0) {
             out[0] = 30;
@@ -1023,6 +1053,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
     if (mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
         mode = (int)prm.trial_res[fid].chosen;
+    }
 
     // Candidate bookkeeping and pruning exactly as in k_compress (atsc_kernels.hip): the selector keeps
     // the smallest passing payload, first of [FFT, Polynomial, RLE] on ties, and a ladder's payload
@@ -1033,8 +1064,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     const bool run_rle = (mode == ATSC_AUTO || mode == ATSC_RLE);
     const double me = prm.max_err;
     const bool prune = (mode == ATSC_AUTO) && (0.0 <= me);
-    uint32_t best_size = 0xFFFFFFFFu;
-    int best_owner = 3;
+    uint32_t best_size = PART == 2 ? fst->best_size : 0xFFFFFFFFu;
+    int best_owner = PART == 2 ? fst->best_owner : 3;
     auto can_win = [&](uint32_t size_lb, int owner) {
         return size_lb < best_size || (size_lb == best_size && owner < best_owner);
     };
@@ -1046,6 +1077,11 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     // ---- RLE (rle.rs:142-189): bound first; exact right away when there are few runs ----
     uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0, rle_lb = 0xFFFFFFFFu;
     bool rle_sorted = false, rle_pending = false;
+    if (PART == 2) {
+        rle_size = fst->rle_size; rle_R = fst->rle_R; rle_D = fst->rle_D; rle_ib = fst->rle_ib; rle_lb = fst->rle_lb;
+        rle_sorted = (fst->flags & 1u) != 0;
+        rle_pending = (fst->flags & 2u) != 0;
+    }
     auto run_key = [&](uint64_t rec) { return (uint64_t)__double_as_longlong(xs[(uint32_t)rec]); };
     auto rle_sort_and_group = [&]() {
         __syncthreads();
@@ -1146,7 +1182,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         rle_size = 2 + vlen(D) + hb + rle_ib;
         rle_sorted = true;
     };
-    if (run_rle) {
+    if (PART != 2 && run_rle) {
         rle_R = block_sum_u32<W>(st_runs, red, parity);  // counted with the statistics
         rle_ib = block_sum_u32<W>(st_ibytes, red, parity);
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
@@ -1174,6 +1210,13 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     bool poly_done = false, poly_pruned = false, poly_active = false;
     double pcur = prm.max_err + 1.0;
     uint32_t pjump = 0;
+    if (PART == 2) {
+        poly_step = fst->poly_step; poly_K = fst->poly_K; poly_size = fst->poly_size; poly_trips = fst->poly_trips;
+        poly_err = fst->poly_err; pcur = fst->pcur; pjump = fst->pjump;
+        poly_done = (fst->flags & 4u) != 0;
+        poly_pruned = (fst->flags & 8u) != 0;
+        poly_active = (fst->flags & 16u) != 0;
+    }
     auto poly_ladder = [&](uint32_t limit) {
             const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
             const uint32_t dj1 = max(n / 10, 1u), dj2 = max(n / 100, 1u);
@@ -1343,7 +1386,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         dg.poly_size = poly_size; dg.poly_trips = (uint16_t)poly_trips;
         dg.poly_step = (uint16_t)poly_step; dg.poly_points = poly_K; dg.poly_err = poly_err;
     };
-    if (run_poly) {
+    if (PART != 2 && run_poly) {
         if (smax == smin) {
             poly_K = 0;
             poly_step = 1;
@@ -1585,14 +1628,15 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             const uint32_t K1 = min(P.mf, Z);
             const bool fft_hopeless = prune && !can_win(1 + vlen(K1) + 9 * K1 + 8, 0);
             if (fft_hopeless) fft_pruned = true;
-            uint32_t nkeys = fft_hopeless ? 0u : build_order(min(kcap_total, max(4096u, P.mf + 4 * P.dk1)));
+            uint32_t nkeys = PART == 2 ? fst->nkeys
+                             : fft_hopeless ? 0u : build_order(min(kcap_total, max(4096u, P.mf + 4 * P.dk1)));
             if (prm.debug_stop == 5) return;
 
             // ---- ladder ----
             const bool wraps = bins > 65536;
             const bool sparse = prm.sparse_inv != 0 && P.sp_mf != 0;
             uint32_t *own = aux;
-            if (wraps) {
+            if (wraps && PART != 2) {
                 for (uint32_t i = tid; i < 65536; i += T) own[i] = 0;
                 __syncthreads();
             }
@@ -1601,8 +1645,22 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             const float Lf = (float)L;
             uint32_t used = 0, jump = 0;
             double cur = prm.max_err + 1.0;
+            bool resume = (PART == 2);  // PART 2 enters the loop where PART 1 left it: first trip admitted and bucketed
+            if (PART == 2) { used = fst->used; fft_trips = 1; }
+            auto sel_entry = [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+                const Sel e = sel[i];
+                p = e.pos;
+                if (wraps) {
+                    p &= 0xffffu;
+                    if (own[p] != i + 1) return false;
+                }
+                x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
+                return true;
+            };
             while (!fft_hopeless && (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0))) {
-                uint32_t K = min(P.mf + jump, Z);
+                uint32_t K = used;
+                if (!resume) {
+                K = min(P.mf + jump, Z);
                 if (K > nkeys && nkeys < min(kcap_total, bins)) nkeys = build_order(kcap_total);  // same prefix, longer
                 K = min(K, nkeys);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
@@ -1631,21 +1689,44 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 }
                 used = K;
                 if (!prm.bounded) { cur = 0.0; break; }
+                }
                 double s = 0.0;
-                if (sparse) {
+                if (sparse && resume) {
+                    // the tiles of this trip ran in k_large_trip_tiles: their sums, in tile order
+                    if (tid == 0) {
+                        const double *part = (const double *)((const unsigned char *)Cb + TRIP_PARTIAL_OFF);
+                        for (uint32_t t = 0; t < (P.sp_md + SPB - 1) / SPB; ++t) s += part[t];
+                    }
+                } else if (sparse) {
+                    if (PART == 1 && fft_trips == 1) {
+                        // the cut: bucket the list, leave the bounds and the state, the tiles run elsewhere
+                        sparse_bucket(P, K, sel_entry, (SpEnt *)work, tw, (unsigned char *)keys, wsum);
+                        const SpLds sl = sp_lds(P, (unsigned char *)keys);
+                        uint32_t *gb = (uint32_t *)((unsigned char *)Cb + TRIP_BOUNDS_OFF);
+                        for (uint32_t e = tid; e < P.sp_mf; e += T) {
+                            gb[e] = sl.beg[e];
+                            gb[P.sp_mf + e] = sl.end[e];
+                        }
+                        if (tid == 0) {
+                            TripState f;
+                            f.smin = smin; f.smax = smax; f.poly_err = poly_err; f.pcur = pcur;
+                            f.dg = dg;
+                            f.finished = 0;
+                            f.bitdepth = bitdepth; f.rle_size = rle_size; f.rle_R = rle_R; f.rle_D = rle_D;
+                            f.rle_ib = rle_ib; f.rle_lb = rle_lb; f.best_size = best_size;
+                            f.poly_step = poly_step; f.poly_K = poly_K; f.poly_size = poly_size;
+                            f.poly_trips = poly_trips; f.pjump = pjump;
+                            f.Z = Z; f.nkeys = nkeys; f.used = used;
+                            f.mode = mode; f.best_owner = best_owner;
+                            f.flags = (rle_sorted ? 1u : 0u) | (rle_pending ? 2u : 0u) | (poly_done ? 4u : 0u) |
+                                      (poly_pruned ? 8u : 0u) | (poly_active ? 16u : 0u);
+                            *fst = f;
+                        }
+                        return;
+                    }
                     // evaluate: idata[j].re / L (f32), round 5, clamp, MAPE against the padded signal
                     sparse_inverse(
-                        P, K,
-                        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
-                            const Sel e = sel[i];
-                            p = e.pos;
-                            if (wraps) {
-                                p &= 0xffffu;
-                                if (own[p] != i + 1) return false;
-                            }
-                            x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
-                            return true;
-                        },
+                        P, K, sel_entry,
                         (SpEnt *)work, tw, (unsigned char *)keys, wsum,
                         [&](uint32_t j) -> double { return gpad(j); },
                         [&](uint32_t, float re, double g) {
@@ -1700,6 +1781,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     s += fabs((o - g) / g);
                 }
                 }
+                resume = false;
                 s = block_sum_f64<W>(s, red, parity);
                 cur = s / Ld;
                 if (fft_trips <= 17) jump += P.dk1;
@@ -1878,6 +1960,61 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
 }
 
+// One tile (SPB output columns) of the first FFT trip of one frame whose k_compress_large<1> stopped at the cut:
+// the tile's share of the MAPE sum goes to the frame's workspace (buffer C, TRIP_PARTIAL_OFF).
+__global__ __launch_bounds__(LT) void k_large_trip_tiles(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+    const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const DevFrame fr = frames[ids[blockIdx.y]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t jb0 = blockIdx.x * SPB;
+    if (!P.sp_mf || jb0 >= P.sp_md) return;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
+    const TripState *fst = (const TripState *)(ws + lay.o_front);
+    if (fst->finished) return;
+    const uint32_t n = P.n, L = P.L, pre = P.pre, Mf = P.sp_mf, Md = P.sp_md;
+    const float2 *tw = twpool + P.tw_off;
+    const double *xs = samples + fr.sample_off;
+    const SpLds sl = sp_lds(P, smem);
+    double *red = (double *)(smem + SP_LDS_BYTES);
+    unsigned char *Cb = ws + lay.o_c;
+    const uint32_t *gb = (const uint32_t *)(Cb + TRIP_BOUNDS_OFF);
+    for (uint32_t e = tid; e < Mf; e += LT) {
+        sl.wf[e] = tw[e * (L / Mf)];
+        sl.beg[e] = gb[e];
+        sl.end[e] = gb[Mf + e];
+    }
+    for (uint32_t e = tid; e < Md; e += LT) sl.wd[e] = tw[e * (L / Md)];
+    __syncthreads();
+    // the list sits in the FFT buffer that does not hold the spectrum (see k_compress_large: spec / work)
+    const SpEnt *zl = (const SpEnt *)(ws + (P.half ? lay.o_a : lay.o_b));
+    const double mxd = (double)(float)fst->smax, mnd = (double)(float)fst->smin;
+    const float Lf = (float)L;
+    double s = 0.0;
+    sparse_tile(
+        P, jb0, zl, tw, smem,
+        [&](uint32_t j) -> double {  // fft.rs:184-204
+            int32_t i = (int32_t)j - (int32_t)pre;
+            i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
+            return xs[i];
+        },
+        [&](uint32_t, float re, double g) {
+            const double v = (double)(re / Lf);
+            double o = div1e5(round(v * 100000.0));
+            if (o > mxd) o = mxd;
+            if (o < mnd) o = mnd;
+            s += fabs(o - g) * recip_abs(g);
+        });
+    int parity = 0;
+    s = block_sum_f64<LW>(s, red, parity);
+    if (tid == 0) ((double *)(Cb + TRIP_PARTIAL_OFF))[blockIdx.x] = s;
+}
+
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
@@ -1885,11 +2022,24 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const LargePre *pre)
 {
     const uint32_t lds = 384 + 1024 + 64 + max(8 * LKEYS_MAX, SP_LDS_BYTES);
-    hipError_t e = hipFuncSetAttribute((const void *)k_compress_large,
+    hipError_t e = hipFuncSetAttribute((const void *)k_compress_large<0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     KParams kp = prm;
     kp.prefft = (pre && pre->tiles1) ? 1u : 0u;
+    // Few large frames: each has a CU to itself and most CUs idle, so the tiles of the first FFT trip run as
+    // a (tile, frame) grid between the two parts of the per-frame kernel.
+    const bool split = kp.prefft && kp.sparse_inv && kp.bounded && kp.debug_stop == 0 && !kp.trial && pre->sp_tiles &&
+                       count <= LARGE_SPLIT_MAX;
+    const uint32_t lds_tiles = SP_LDS_BYTES + 512;
+    if (split) {
+        e = hipFuncSetAttribute((const void *)k_compress_large<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_compress_large<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_large_trip_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles);
+        if (e != hipSuccess) return e;
+    }
     // tile buffers of a pre-pass workgroup: two of FB x (sub-transform length [+ 1]) points + its twiddles
     uint32_t lds1 = 0, lds2 = 0;
     if (kp.prefft) {
@@ -1910,8 +2060,17 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             hipLaunchKernelGGL(k_large_pre3, dim3(pre->chunks, nb), dim3(PT3), 0, s, samples, frames, ids + b0,
                                plans, twpool, ws, ws_stride, (int)kp.sparse_inv);
         }
-        hipLaunchKernelGGL(k_compress_large, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
-                           twpool, kp, slots, res, diag, ws, ws_stride);
+        if (split) {
+            hipLaunchKernelGGL(k_compress_large<1>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, diag, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_trip_tiles, dim3(pre->sp_tiles, nb), dim3(LT), lds_tiles, s, samples, frames,
+                               ids + b0, plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_compress_large<2>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, diag, ws, ws_stride);
+        } else {
+            hipLaunchKernelGGL(k_compress_large<0>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, diag, ws, ws_stride);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
