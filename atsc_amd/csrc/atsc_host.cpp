@@ -119,7 +119,7 @@ struct atsc_plan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;        // form of the large tier's in-kernel transforms
-    LargePre large_pre{0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
     // atsc_compress_plan_dev_pipelined: a second scratch set (allocated on first use) so that the
     // packing of batch i (context's pack stream) overlaps the codecs of batch i+1 (caller's stream)
     struct Scratch {
@@ -154,7 +154,7 @@ struct atsc_dplan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;
-    LargePre large_pre{0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
     uint32_t large_sp_tiles = 0;        // tiles per frame of the sparse inverse's (tile, frame) grid (0: off)
 };
 
@@ -268,17 +268,18 @@ static bool large_sparse() { return getenv("ATSC_LARGE_DENSE") == nullptr; }
 // the whole GPU before the per-frame kernel); all zero when a large frame length has no M1 x M2 split.
 static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
 {
-    LargePre pre{0, 0, 0, 0, 0, 0};
+    LargePre pre{0, 0, 0, 0, 0, 0, 0};
     if (getenv("ATSC_LARGE_NO_PREPASS")) return pre;
     for (uint32_t pi : large_plan_ids) {
         const DevPlan &p = plans[pi];
-        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0};
+        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0, 0};
         pre.tiles1 = std::max(pre.tiles1, (p.f4_m2 + 15) / 16);
         pre.tiles2 = std::max(pre.tiles2, (p.f4_m1 + 15) / 16);
         pre.chunks = std::max(pre.chunks, (p.bins + 255) / 256);
         pre.m1_max = std::max(pre.m1_max, p.f4_m1);
         pre.m2_max = std::max(pre.m2_max, p.f4_m2);
         if (p.sp_mf) pre.sp_tiles = std::max(pre.sp_tiles, (p.sp_md + 7) / 8);
+        pre.chunks_n = std::max(pre.chunks_n, (p.n + 4095) / 4096);
     }
     if (getenv("ATSC_LARGE_NO_TRIP_TILES")) pre.sp_tiles = 0;
     return pre;
@@ -926,6 +927,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.large_tiled = 0;
     prm.sparse_inv = large_sparse() ? 1u : 0u;
     prm.prefft = 0;
+    prm.prestats = 0;
     if (compressor == ATSC_AUTO && sample_level > 0) {
         if (!plan->trials[sample_level]) {
             SubPlan *t = nullptr;

@@ -118,6 +118,8 @@ struct KParams {
     uint32_t *cost;              // per frame: shader clocks / 64 this launch took (scheduling hint), or null
     uint32_t large_tiled;        // large tier: in-kernel transforms take the LDS-tiled two-pass form
     uint32_t sparse_inv;         // large tier: per-trip inverse transform from the sparse bin list
+    uint32_t prestats;           // large tier, split run: the statistics (LargeStats) and the chunk sums of the first
+                                 // polynomial trip are in the frame's workspace slot (k_large_stats, k_large_poly1)
     uint32_t prefft;             // large tier: forward transform, untangle and norms were done by the
                                  // batched pre-pass kernels (spectrum, norm bits and non-zero count are
                                  // in the frame's workspace slot)
@@ -127,6 +129,7 @@ struct LargePre {
     uint32_t tiles1, tiles2, chunks;  // max over frame lengths: column tiles, row tiles, 256-bin chunks
     uint32_t m1_max, m2_max;          // longest sub-transforms: size the tile buffers in LDS
     uint32_t sp_tiles;                // most tiles (8 output columns each) the sparse inverse of a frame has
+    uint32_t chunks_n;                // most 4096-sample chunks a frame has (k_large_stats, k_large_poly1)
 };
 constexpr uint32_t LARGE_SPLIT_MAX = 128;  // large frames per launch up to which the first FFT trip's tiles
                                            // run as a (tile, frame) grid (launch_compress_large)

@@ -331,7 +331,7 @@ DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw,
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, o_part, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -354,6 +354,7 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_spos = o; o += lw_align(4ull * (16384 + 8));  // admission order (bin positions) once sorted: frees the LDS
     w.o_cnt = o; o += lw_align(16);                   // pre-pass: number of ZERO bins (rare: few atomics)
     w.o_front = o; o += lw_align(256);                // k_compress_large<1> -> <2>: TripState
+    w.o_part = o; o += lw_align(8 * 64);              // k_large_poly1: MAPE sums of the chunks of the first polynomial trip
     w.bytes = o;
     return w;
 }
@@ -855,6 +856,210 @@ __global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ s
 // --------------------------------------------------------------------------------------------
 constexpr uint32_t LKEYS_MAX = 16384;  // LDS sort capacity (kcap of a 131072-sample frame is 13100)
 
+// --------------------------------------------------------------------------------------------
+// Few large frames (split run, see launch_compress_large): the frame statistics and the first polynomial
+// trip, both plain walks over the samples, run as (chunk, frame) grids over the whole GPU before the
+// per-frame kernel instead of inside it on the frame's one CU.
+// --------------------------------------------------------------------------------------------
+constexpr uint32_t LCH = 4096;  // samples per chunk
+struct LargeStats {             // at o_cnt; `zeros` is the pre-pass's count of zero bins (k_large_pre3)
+    uint32_t zeros, frac, runs, ibytes;
+    unsigned long long kmin, kmax;  // min / max as order-preserving integer keys (integer atomics combine chunks)
+};
+DEVI unsigned long long f64_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+DEVI double f64_unkey(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+__global__ void k_large_stats0(const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+                               const DevPlan *__restrict__ plans, unsigned char *__restrict__ ws_base,
+                               uint64_t ws_stride)
+{
+    const DevPlan &P = plans[frames[ids[blockIdx.x]].plan];
+    const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
+    if (threadIdx.x == 0) {
+        LargeStats *st = (LargeStats *)(ws_base + (uint64_t)blockIdx.x * ws_stride + lay.o_cnt);
+        st->zeros = st->frac = st->runs = st->ibytes = 0;
+        st->kmin = ~0ull;
+        st->kmax = 0ull;
+    }
+}
+// utils/mod.rs min / max scan with plain `<` `>`, optimizer/utils.rs split_n, rle.rs run starts -- one chunk
+__global__ __launch_bounds__(LT) void k_large_stats(const double *__restrict__ samples,
+                                                    const DevFrame *__restrict__ frames,
+                                                    const uint32_t *__restrict__ ids,
+                                                    const DevPlan *__restrict__ plans,
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    __shared__ double sred[64];
+    __shared__ uint32_t ured[48];
+    const uint32_t tid = threadIdx.x;
+    const DevFrame fr = frames[ids[blockIdx.y]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, c0 = blockIdx.x * LCH;
+    if (c0 >= n) return;
+    const uint32_t c1 = min(c0 + LCH, n);
+    const double *xs = samples + fr.sample_off;
+    double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
+    uint32_t frac = 0, runs = 0, ib = 0;
+    double v[LCH / LT], pv[LCH / LT];
+#pragma unroll
+    for (uint32_t u = 0; u < LCH / LT; ++u) {
+        const uint32_t j = c0 + u * LT + tid;
+        v[u] = pv[u] = 0.0;
+        if (j < c1) {
+            v[u] = xs[j];
+            if (j) pv[u] = xs[j - 1];
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < LCH / LT; ++u) {
+        const uint32_t j = c0 + u * LT + tid;
+        if (j < c1) {
+            frac |= frac_nonzero(v[u]) ? 1u : 0u;
+            if (v[u] > mx) mx = v[u];
+            if (v[u] < mn) mn = v[u];
+            if (j == 0 || v[u] != pv[u]) { ++runs; ib += vlen(j); }
+        }
+    }
+    const double wmn = wave_minmax_f64<true>(mn), wmx = wave_minmax_f64<false>(mx);
+    const uint32_t wfr = wave_sum_u32(frac), wru = wave_sum_u32(runs), wib = wave_sum_u32(ib);
+    if ((tid & 63) == 0) {
+        sred[tid >> 6] = wmn; sred[16 + (tid >> 6)] = wmx;
+        ured[tid >> 6] = wfr; ured[16 + (tid >> 6)] = wru; ured[32 + (tid >> 6)] = wib;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = sred[0], b = sred[16];
+        uint32_t f = 0, r = 0, i2 = 0;
+        for (uint32_t w = 0; w < LT / 64; ++w) {
+            if (sred[w] < a) a = sred[w];
+            if (sred[16 + w] > b) b = sred[16 + w];
+            f += ured[w]; r += ured[16 + w]; i2 += ured[32 + w];
+        }
+        const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
+        LargeStats *st = (LargeStats *)(ws_base + (uint64_t)blockIdx.y * ws_stride + lay.o_cnt);
+        if (a == a && a <= b) {  // the chunk held at least one comparable sample
+            atomicMin(&st->kmin, f64_key(a));
+            atomicMax(&st->kmax, f64_key(b));
+        }
+        if (f) atomicOr(&st->frac, 1u);
+        if (r) atomicAdd(&st->runs, r);
+        if (i2) atomicAdd(&st->ibytes, i2);
+    }
+}
+// First trip of the polynomial ladder (polynomial.rs:209-277: points = max(3, n/100), the plan's pstep[0] /
+// pK[0]), Catmull-Rom with the tables of k_compress_large: one chunk's share of the MAPE sum.  Clamp range
+// from k_large_stats.
+__global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ samples,
+                                                    const DevFrame *__restrict__ frames,
+                                                    const uint32_t *__restrict__ ids,
+                                                    const DevPlan *__restrict__ plans,
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    __shared__ double4 hbt[256];
+    __shared__ double2 mms[LCH / 2 + 4];
+    __shared__ double red[48];
+    const uint32_t tid = threadIdx.x;
+    const DevFrame fr = frames[ids[blockIdx.y]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, c0 = blockIdx.x * LCH;
+    if (c0 >= n) return;
+    const uint32_t c1 = min(c0 + LCH, n);
+    const uint32_t step = P.pstep[0], K = P.pK[0];
+    if (step <= 1 || step > 256 || K < 2) return;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
+    const LargeStats *st = (const LargeStats *)(ws + lay.o_cnt);
+    const double smin = f64_unkey(st->kmin), smax = f64_unkey(st->kmax);
+    const double *xs = samples + fr.sample_off;
+    const uint32_t magic = P.pmagic[0];
+    const uint32_t gapL = (n - 1) - (K - 2) * step;
+    const double stepd = (double)step, gapLd = (double)gapL;
+    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+    // segments this chunk touches: sgA .. sgB
+    uint32_t sgA = __umulhi(c0, magic), sgB = __umulhi(c1 - 1, magic);
+    if (sgA > K - 2) sgA = K - 2;
+    if (sgB > K - 2) sgB = K - 2;
+    for (uint32_t sg = sgA + tid; sg <= sgB; sg += LT) {
+        double2 t = make_double2(0.0, 0.0);
+        if (sg >= 1 && sg + 2 < K) {
+            const uint32_t t0i = sg * step;
+            const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+            const uint32_t tmi = (sg - 1) * step;
+            const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+            const double t0 = (double)t0i, t1 = (double)t1i;
+            const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+            t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+            t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+        }
+        mms[sg - sgA] = t;
+    }
+    for (uint32_t r = tid; r < step; r += LT) {
+        const double nt = div_small((double)r, stepd, ry);
+        const double t2 = nt * nt;
+        const double t3 = t2 * nt;
+        const double two_t3 = t3 * 2.0;
+        const double two_t2 = t2 * 2.0;
+        const double three_t2 = t2 * 3.0;
+        double4 h;
+        h.x = two_t3 - three_t2 + 1.0;
+        h.y = t3 - two_t2 + nt;
+        h.z = three_t2 - two_t3;
+        h.w = t3 - t2;
+        hbt[r] = h;
+    }
+    __syncthreads();
+    double s = 0.0;
+    double g[LCH / LT], v0[LCH / LT], v1[LCH / LT];
+#pragma unroll
+    for (uint32_t u = 0; u < LCH / LT; ++u) {
+        const uint32_t i = c0 + u * LT + tid;
+        g[u] = v0[u] = v1[u] = 0.0;
+        if (i < c1) {
+            uint32_t sg = __umulhi(i, magic);
+            if (sg > K - 2) sg = K - 2;
+            const uint32_t t0i = sg * step;
+            g[u] = xs[i];
+            v0[u] = xs[t0i];
+            v1[u] = xs[(sg == K - 2) ? (n - 1) : t0i + step];
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < LCH / LT; ++u) {
+        const uint32_t i = c0 + u * LT + tid;
+        if (i >= c1) continue;
+        double sv;
+        if (i == n - 1) {
+            sv = g[u];
+        } else {
+            uint32_t sg = __umulhi(i, magic);
+            if (sg > K - 2) sg = K - 2;
+            const uint32_t t0i = sg * step;
+            const bool last = (sg == K - 2);
+            if (sg > 0 && !last) {
+                const double2 t = mms[sg - sgA];
+                const double4 h = hbt[i - t0i];
+                sv = v0[u] * h.x + t.x * h.y + v1[u] * h.z + t.y * h.w;
+            } else {
+                const double nt = div_small((double)(i - t0i), last ? gapLd : stepd, last ? ryL : ry);
+                sv = v0[u] * (1.0 - nt) + v1[u] * nt;
+            }
+        }
+        double o = div1e5(round(sv * 100000.0));
+        if (o < smin) o = smin;
+        else if (o > smax) o = smax;
+        s += fabs((o - g[u]) / g[u]);
+    }
+    int parity = 0;
+    s = block_sum_f64<LW>(s, red, parity);
+    if (tid == 0) ((double *)(ws + lay.o_part))[blockIdx.x] = s;
+}
+
 // What the first part of a split run hands to the second (PART 1 -> k_large_trip_tiles -> PART 2)
 struct TripState {
     double smin, smax, poly_err, pcur;
@@ -951,6 +1156,17 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         const double x0 = xs[0];
         double mn = x0, mx = x0;
         uint32_t fr_any = 0;
+        if (prm.prestats) {
+            // k_large_stats walked the samples already (LargeStats); a NaN first sample keeps the reference's
+            // outcome of a scan that starts from it
+            const LargeStats *lst = (const LargeStats *)(ws + lay.o_cnt);
+            if (x0 == x0) {
+                mn = f64_unkey(lst->kmin);
+                mx = f64_unkey(lst->kmax);
+            }
+            fr_any = lst->frac;
+            if (tid == 0) { st_runs = lst->runs; st_ibytes = lst->ibytes; }
+        } else {
         auto visit = [&](uint32_t j, double v, double prev) {
             fr_any |= frac_nonzero(v) ? 1u : 0u;
             if (v > mx) mx = v;
@@ -986,6 +1202,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             j0 = 2 * np;
         }
         for (uint32_t j = j0 + tid; j < n; j += T) visit(j, xs[j], j ? xs[j - 1] : 0.0);
+        }
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
         // The extremes are reported with the bits of their first occurrence.  Doubles that compare
@@ -1269,6 +1486,15 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         else if (o > smax) o = smax;
                         const double g = xs[i];
                         s += fabs((o - g) / g);
+                    }
+                    s = block_sum_f64<W>(s, red, parity);
+                    cur = s / (double)n;
+                } else if (step > 1 && prm.prestats && poly_trips == 1 && step <= 256 && xs[0] == xs[0]) {
+                    // k_large_poly1 evaluated this trip chunk by chunk: the sums, in chunk order
+                    double s = 0.0;
+                    if (tid == 0) {
+                        const double *part = (const double *)(ws + lay.o_part);
+                        for (uint32_t c = 0; c < (n + LCH - 1) / LCH; ++c) s += part[c];
                     }
                     s = block_sum_f64<W>(s, red, parity);
                     cur = s / (double)n;
@@ -2032,6 +2258,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     const bool split = kp.prefft && kp.sparse_inv && kp.bounded && kp.debug_stop == 0 && !kp.trial && pre->sp_tiles &&
                        count <= LARGE_SPLIT_MAX;
     const uint32_t lds_tiles = SP_LDS_BYTES + 512;
+    kp.prestats = (split && pre->chunks_n) ? 1u : 0u;
     if (split) {
         e = hipFuncSetAttribute((const void *)k_compress_large<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -2052,6 +2279,16 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
+        if (split) {
+            // statistics and first polynomial trip as (chunk, frame) grids; k_large_pre1 then resets the count of
+            // zero bins only
+            hipLaunchKernelGGL(k_large_stats0, dim3(nb), dim3(64), 0, s, frames, ids + b0, plans, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_stats, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
+                               ws, ws_stride);
+            if (kp.mode == ATSC_AUTO)
+                hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0,
+                                   plans, ws, ws_stride);
+        }
         if (kp.prefft) {
             hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames,
                                ids + b0, plans, twpool, ws, ws_stride);
