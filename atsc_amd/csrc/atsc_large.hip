@@ -2191,15 +2191,20 @@ __global__ __launch_bounds__(LT) void k_compress_large(
 __global__ __launch_bounds__(LT) void k_large_trip_tiles(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
-    const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+    const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base, uint64_t ws_stride, uint32_t nframes)
 {
+    // grid (frames padded to a multiple of 8, tiles): workgroups are dealt round-robin over the 8 XCDs by
+    // their linear index, so the tiles of a frame -- which share its list, twiddles and samples -- land on one
+    // XCD and its L2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const DevFrame fr = frames[ids[blockIdx.y]];
+    const uint32_t fidx = blockIdx.x;
+    if (fidx >= nframes) return;
+    const DevFrame fr = frames[ids[fidx]];
     const DevPlan &P = plans[fr.plan];
-    const uint32_t jb0 = blockIdx.x * SPB;
+    const uint32_t jb0 = blockIdx.y * SPB;
     if (!P.sp_mf || jb0 >= P.sp_md) return;
-    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    unsigned char *ws = ws_base + (uint64_t)fidx * ws_stride;
     const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
     const TripState *fst = (const TripState *)(ws + lay.o_front);
     if (fst->finished) return;
@@ -2238,7 +2243,7 @@ __global__ __launch_bounds__(LT) void k_large_trip_tiles(
         });
     int parity = 0;
     s = block_sum_f64<LW>(s, red, parity);
-    if (tid == 0) ((double *)(Cb + TRIP_PARTIAL_OFF))[blockIdx.x] = s;
+    if (tid == 0) ((double *)(Cb + TRIP_PARTIAL_OFF))[blockIdx.y] = s;
 }
 
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
@@ -2300,8 +2305,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         if (split) {
             hipLaunchKernelGGL(k_compress_large<1>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, diag, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_trip_tiles, dim3(pre->sp_tiles, nb), dim3(LT), lds_tiles, s, samples, frames,
-                               ids + b0, plans, twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_trip_tiles, dim3((nb + 7u) & ~7u, pre->sp_tiles), dim3(LT), lds_tiles, s, samples,
+                               frames, ids + b0, plans, twpool, ws, ws_stride, nb);
             hipLaunchKernelGGL(k_compress_large<2>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, diag, ws, ws_stride);
         } else {
@@ -2755,16 +2760,19 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
 __global__ __launch_bounds__(LT) void k_decompress_large_tiles(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, double *__restrict__ outp,
-    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, uint32_t nframes)
 {
+    // grid (frames padded to a multiple of 8, tiles): a frame's tiles share one XCD (see k_large_trip_tiles)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const DevDFrame fr = frames[ids[blockIdx.y]];
+    const uint32_t fidx = blockIdx.x;
+    if (fidx >= nframes) return;
+    const DevDFrame fr = frames[ids[fidx]];
     if (fr.tag != ATSC_FFT) return;
     const DevPlan &P = plans[fr.plan];
-    const uint32_t jb0 = blockIdx.x * SPB;
+    const uint32_t jb0 = blockIdx.y * SPB;
     if (!P.sp_mf || jb0 >= P.sp_md) return;
-    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    unsigned char *ws = ws_base + (uint64_t)fidx * ws_stride;
     const LargeWs lay = large_ws_layout(fr.n, P.L, P.kcap);
     const DecPending *pend = (const DecPending *)(ws + lay.o_cnt);
     if (pend->pending != 2) return;
@@ -2845,8 +2853,8 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
                                body, out, status, ws, ws_stride, tiled, sparse, sp_split);
             if (sp_split)
-                hipLaunchKernelGGL(k_decompress_large_tiles, dim3(sp_tiles, nb), dim3(LT), SP_LDS_BYTES, s, frames,
-                                   ids + b0, plans, twpool, out, ws, ws_stride);
+                hipLaunchKernelGGL(k_decompress_large_tiles, dim3((nb + 7u) & ~7u, sp_tiles), dim3(LT), SP_LDS_BYTES, s,
+                                   frames, ids + b0, plans, twpool, out, ws, ws_stride, nb);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
