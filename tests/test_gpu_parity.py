@@ -952,3 +952,36 @@ def test_large_frames_sparse_and_dense_inverse_agree(ctx, A, oracle, monkeypatch
                 assert np.max(np.abs(out_s[seg] - ref[seg])) <= t and np.max(np.abs(out_d[seg] - ref[seg])) <= t, (comp, i)
             else:
                 assert np.array_equal(out_s[seg], ref[seg]) and np.array_equal(out_d[seg], ref[seg]), (comp, i)
+
+
+def test_large_frames_grid_and_single_kernel_forms_agree(ctx, A, monkeypatch):
+    """A batch of few large frames runs its sample walks and the first FFT trip's tiles as grids over the whole
+    GPU (k_large_stats, k_large_poly1, k_large_trip_tiles, k_decompress_large_tiles); ATSC_LARGE_NO_TRIP_TILES /
+    ATSC_LARGE_DECODE_ONE_KERNEL keep everything of a frame on its own workgroup.  Same arithmetic per sample,
+    different summation order of the error sums: same codecs and bytes (unless a frame sits on a decision
+    threshold), errors equal to summation-order accuracy, decoded samples identical."""
+    sizes = [4097, 6561, 8192, 20000, 65536, 131072, 131072]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in (0, 1, 2, 3):
+            xs.append(H.synth_series(1300 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    for comp, me in ((A.AUTO, ME5), (A.AUTO, ME1), (A.FFT, ME5)):
+        rec_g, _, ch_g, err_g = ctx.compress_host(x, off, comp, True, me, 0)
+        out_g = ctx.decompress_host(rec_g)
+        monkeypatch.setenv("ATSC_LARGE_NO_TRIP_TILES", "1")
+        monkeypatch.setenv("ATSC_LARGE_DECODE_ONE_KERNEL", "1")
+        rec_1, _, ch_1, err_1 = ctx.compress_host(x, off, comp, True, me, 0)
+        out_1 = ctx.decompress_host(rec_g)
+        monkeypatch.delenv("ATSC_LARGE_NO_TRIP_TILES")
+        monkeypatch.delenv("ATSC_LARGE_DECODE_ONE_KERNEL")
+        assert np.array_equal(ch_g, ch_1)
+        fg = H.parse_bro_body(rec_g, with_count=False)
+        f1 = H.parse_bro_body(rec_1, with_count=False)
+        differ = sum(1 for a, b in zip(fg, f1) if a != b)
+        assert differ <= 1, (comp, me, differ)
+        if not differ:
+            assert np.allclose(err_g, err_1, rtol=1e-9, atol=1e-15, equal_nan=True)
+        assert np.array_equal(out_g, out_1, equal_nan=True)
