@@ -1688,9 +1688,9 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 __syncthreads();
                 Z = block_sum_u32<W>(nz, red, parity);
             }
-            // The order is built for the bins the first trips can ask for and extended to the full
-            // kcap only if the ladder gets that far: sorting 4096 keys instead of 16384 takes a third
-            // of the time, and at e = 5 % few frames go beyond a handful of trips.
+            // The order is built for the bins the first two trips can ask for (2048 keys), extended to
+            // five trips' worth (4096) and to the full kcap only if the ladder gets that far: the sort is
+            // most of the cost, and at e = 5 % few frames go beyond a trip or two.
             const uint32_t kcap_total = min(P.kcap, LKEYS_MAX);
             auto build_order = [&](const uint32_t kcap) -> uint32_t {
             uint32_t nkeys = 0;
@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             const bool fft_hopeless = prune && !can_win(1 + vlen(K1) + 9 * K1 + 8, 0);
             if (fft_hopeless) fft_pruned = true;
             uint32_t nkeys = PART == 2 ? fst->nkeys
-                             : fft_hopeless ? 0u : build_order(min(kcap_total, max(4096u, P.mf + 4 * P.dk1)));
+                             : fft_hopeless ? 0u : build_order(min(kcap_total, max(2048u, P.mf + P.dk1)));
             if (prm.debug_stop == 5) return;
 
             // ---- ladder ----
@@ -1887,7 +1887,9 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 uint32_t K = used;
                 if (!resume) {
                 K = min(P.mf + jump, Z);
-                if (K > nkeys && nkeys < min(kcap_total, bins)) nkeys = build_order(kcap_total);  // same prefix, longer
+                // (same prefix, longer: first the two trips most frames need, then five, then everything)
+                if (K > nkeys && nkeys < min(kcap_total, bins))
+                    nkeys = build_order(nkeys < 4096u ? min(kcap_total, max(4096u, P.mf + 4 * P.dk1)) : kcap_total);
                 K = min(K, nkeys);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
