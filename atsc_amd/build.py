@@ -31,10 +31,42 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS + [CLI_SRC, CLI2_SRC])
 
 
+OBJDIR = os.path.join(HERE, "build")
+HEADERS = ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
+CFLAGS = [f for f in FLAGS if f != "-shared"]
+
+
+def _obj_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in [src] + HEADERS)
+
+
+def _compile_objects(force, verbose):
+    """One object per source (kept under atsc_amd/build/, git-ignored), compiled side by side: the three
+    kernel files take about a minute each, so an edit to one of them costs one of them."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs, objs = [], []
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _obj_stale(s, obj):
+            cmd = [_hipcc()] + CFLAGS + ["-c", "-o", obj, os.path.join(CSRC, s)]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
+    bad = [s for s, p in jobs if p.wait() != 0]
+    if bad:
+        raise RuntimeError("hipcc failed on " + ", ".join(bad))
+    return objs
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    objs = _compile_objects(force, verbose)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -95,6 +95,7 @@ SIGNATURES = {
     "atsc_next_size": (C.c_uint64, [C.c_uint64]),
     "atsc_bro_prefix": (C.c_uint64, [C.c_uint64, _u8p]),
     "atsc_bro_open": (C.c_int, [_u8p, C.c_uint64, _u64p, _u64p]),
+    "atsc_bro_scan": (C.c_int, [_u8p, C.c_uint64, _u64p, _u64p]),
     # csv-compressor front end (atsc_vsri.cpp)
     "atsc_vsri_new": (_vp, []),
     "atsc_vsri_free": (None, [_vp]),

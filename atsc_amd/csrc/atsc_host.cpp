@@ -454,6 +454,7 @@ extern "C" const char *atsc_strerror(int rc)
 
 extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
 {
+    ATSC_API_BEGIN
     if (!out) return ATSC_E_INVALID;
     *out = nullptr;
     int cnt = 0;
@@ -469,6 +470,7 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
     if (getenv("ATSC_NO_ADAPTIVE_ORDER")) c->adaptive_order = false;
     *out = c;
     return ATSC_OK;
+    ATSC_API_END
 }
 extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
 {
@@ -496,6 +498,7 @@ extern "C" int atsc_ctx_set_profiling(atsc_ctx *ctx, int on)
 }
 extern "C" int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *launches)
 {
+    ATSC_API_BEGIN
     if (!ctx || !total_ms || !launches) return ATSC_E_INVALID;
     double tot = 0.0;
     for (size_t i = 0; i < ctx->ev_used; ++i) {
@@ -508,6 +511,7 @@ extern "C" int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *
     *launches = ctx->ev_used;
     ctx->ev_used = 0;
     return ATSC_OK;
+    ATSC_API_END
 }
 // Diagnostics are opt-in (they add 40 B/frame of HBM writes): enabled by this call.
 extern "C" int atsc_ctx_enable_diag(atsc_ctx *ctx, int on)
@@ -518,11 +522,13 @@ extern "C" int atsc_ctx_enable_diag(atsc_ctx *ctx, int on)
 }
 extern "C" int atsc_ctx_last_diag(atsc_ctx *ctx, atsc_frame_diag *out, uint64_t n_frames)
 {
+    ATSC_API_BEGIN
     if (!ctx || !out) return ATSC_E_INVALID;
     if (!ctx->d_diag || ctx->diag_n != n_frames) return fail(ctx, ATSC_E_INVALID, "no diagnostics recorded");
     HIPCHK(ctx, hipStreamSynchronize(ctx->diag_stream));
     HIPCHK(ctx, hipMemcpy(out, ctx->d_diag, n_frames * sizeof(atsc_frame_diag), hipMemcpyDeviceToHost));
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -571,6 +577,7 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
 extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64_t n_frames,
                                 atsc_plan **out)
 {
+    ATSC_API_BEGIN
     if (!ctx || !frame_off || !out || n_frames == 0) return fail(ctx, ATSC_E_INVALID, "plan_create: bad argument");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -692,6 +699,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
 #undef PCHK
     *out = p;
     return ATSC_OK;
+    ATSC_API_END
 }
 extern "C" uint64_t atsc_plan_n_frames(const atsc_plan *p) { return p ? p->n_frames : 0; }
 extern "C" uint64_t atsc_plan_n_samples(const atsc_plan *p) { return p ? p->n_samples : 0; }
@@ -1020,8 +1028,10 @@ extern "C" int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, cons
                                       uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
                                       uint8_t *d_chosen, double *d_err, void *stream)
 {
+    ATSC_API_BEGIN
     return compress_impl(ctx, plan, d_samples, compressor, bounded, max_error, sample_level, d_body,
                          body_cap, d_rec_off, d_chosen, d_err, stream, false);
+    ATSC_API_END
 }
 extern "C" int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan,
                                                 const double *d_samples, int compressor, int bounded,
@@ -1029,8 +1039,10 @@ extern "C" int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *
                                                 uint64_t body_cap, uint64_t *d_rec_off,
                                                 uint8_t *d_chosen, double *d_err, void *stream)
 {
+    ATSC_API_BEGIN
     return compress_impl(ctx, plan, d_samples, compressor, bounded, max_error, sample_level, d_body,
                          body_cap, d_rec_off, d_chosen, d_err, stream, true);
+    ATSC_API_END
 }
 extern "C" int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on)
 {
@@ -1052,6 +1064,7 @@ extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const 
                                     uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen,
                                     double *err)
 {
+    ATSC_API_BEGIN
     if (!ctx || !samples || !frame_off || !body || !body_len) return fail(ctx, ATSC_E_INVALID, "compress_frames: null argument");
     if (n_frames == 0) return fail(ctx, ATSC_E_INVALID, "compress_frames: no frames");
     // re-base offsets so that frame_off[0] maps to d_x[0]
@@ -1098,6 +1111,7 @@ done:
     pool_free(ctx, d_err);
     atsc_plan_destroy(plan);
     return rc;
+    ATSC_API_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1142,19 +1156,7 @@ static uint32_t host_put_varint(uint8_t *p, uint64_t v)
 }
 static bool host_get_varint(const uint8_t *b, uint64_t len, uint64_t &pos, uint64_t &v)
 {
-    if (pos >= len) return false;
-    const uint8_t t = b[pos];
-    uint32_t nb;
-    if (t < 251) { v = t; pos += 1; return true; }
-    if (t == 251) nb = 2;
-    else if (t == 252) nb = 4;
-    else if (t == 253) nb = 8;
-    else return false;
-    if (pos + 1 + nb > len) return false;
-    v = 0;
-    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)b[pos + 1 + i] << (8 * i);
-    pos += 1 + nb;
-    return true;
+    return host_varint(b, len, pos, v);
 }
 extern "C" uint64_t atsc_bro_prefix(uint64_t n_frames, uint8_t *out)
 {
@@ -1195,74 +1197,114 @@ extern "C" void atsc_dplan_destroy(atsc_dplan *p)
 extern "C" uint64_t atsc_dplan_n_frames(const atsc_dplan *p) { return p ? p->n_frames : 0; }
 extern "C" uint64_t atsc_dplan_n_samples(const atsc_dplan *p) { return p ? p->n_samples : 0; }
 
-extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
-                                 int has_count, atsc_dplan **out)
-{
-    if (!ctx || !body || !out) return fail(ctx, ATSC_E_INVALID, "dplan_create: null argument");
-    *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    uint64_t pos = 0, declared = 0;
-    if (has_count && !host_get_varint(body, body_len, pos, declared))
-        return fail(ctx, ATSC_E_FORMAT, "dplan_create: frame count");
-    atsc_dplan *p = new (std::nothrow) atsc_dplan();
-    if (!p) return ATSC_E_NOMEM;
-    p->ctx = ctx;
+// Host half of atsc_dplan_create: walks the untrusted record bytes and builds the per-frame table and the
+// per-length tables.  No HIP call in here (the sanitizer build of tests/asan drives it without a GPU
+// through atsc_internal_dplan_parse).
+struct DPlanHost {
     std::vector<DevDFrame> frames;
     std::vector<int> cls;
+    PlanTables tabs;
+    std::vector<uint32_t> class_count, class_lds;
+    uint64_t ws_stride = 0, n_samples = 0;
+};
+static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DPlanHost &H, const char **why)
+{
+    uint64_t pos = 0, declared = 0;
+    *why = "";
+    if (has_count && !host_get_varint(body, body_len, pos, declared)) { *why = "dplan_create: frame count"; return ATSC_E_FORMAT; }
+    // untrusted bytes: a declared count can be anything; every record takes at least 4 bytes
+    if (has_count && declared > body_len / 4) { *why = "dplan_create: frame count exceeds the bytes present"; return ATSC_E_FORMAT; }
     std::map<uint32_t, uint64_t> tw_by_L;
-    p->class_count.assign(N_CLASSES, 0);
-    p->class_lds.assign(N_CLASSES, 0);
-    p->class_first.assign(N_CLASSES, 0);
+    H.class_count.assign(N_CLASSES, 0);
+    H.class_lds.assign(N_CLASSES, 0);
     uint64_t out_off = 0;
-    while (has_count ? frames.size() < declared : pos < body_len) {
-        uint64_t fs, sc, tag, dl;
-        if (!host_get_varint(body, body_len, pos, fs) || !host_get_varint(body, body_len, pos, sc) ||
-            !host_get_varint(body, body_len, pos, tag) || !host_get_varint(body, body_len, pos, dl) ||
-            pos + dl > body_len) {
-            atsc_dplan_destroy(p);
-            return fail(ctx, ATSC_E_FORMAT, "dplan_create: truncated frame record");
-        }
-        if (tag > 6 || tag == ATSC_AUTO) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: compressor id"); }
+    while (has_count ? H.frames.size() < declared : pos < body_len) {
+        HostRecord hr;
+        if (!host_next_record(body, body_len, pos, hr)) { *why = "dplan_create: truncated frame record"; return ATSC_E_FORMAT; }
+        const uint64_t sc = hr.sample_count, tag = hr.tag, dl = hr.payload_len;
+        const uint64_t pay = hr.payload_off;
+        if (tag > 6 || tag == ATSC_AUTO) { *why = "dplan_create: compressor id"; return ATSC_E_FORMAT; }
         uint64_t nout = sc;
         if (tag == ATSC_NOOP) {
             // noop_to_data returns the stored vector whatever sample_count says (noop.rs:79-83)
-            uint64_t q = pos + 1, cnt = 0;
-            if (dl < 2 || !host_get_varint(body, pos + dl, q, cnt)) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: noop payload"); }
+            // (every stored value takes at least one byte: a count above the payload length is forged)
+            uint64_t q = pay + 1, cnt = 0;
+            if (dl < 2 || !host_get_varint(body, pay + dl, q, cnt) || cnt > dl) { *why = "dplan_create: noop payload"; return ATSC_E_FORMAT; }
             nout = cnt;
         }
-        if (nout == 0 || nout > MAX_FRAME) {
-            atsc_dplan_destroy(p);
-            return fail(ctx, nout == 0 ? ATSC_E_FORMAT : ATSC_E_UNSUPPORTED, "dplan_create: frame sample count");
-        }
+        if (nout == 0) { *why = "dplan_create: frame sample count"; return ATSC_E_FORMAT; }
+        if (nout > MAX_FRAME) { *why = "dplan_create: frame longer than 131072 samples"; return ATSC_E_UNSUPPORTED; }
         const uint32_t n = (uint32_t)nout;
-        auto it = p->tabs.by_n.find(n);
+        auto it = H.tabs.by_n.find(n);
         uint32_t pi;
-        if (it == p->tabs.by_n.end()) {
-            int rc = build_plan_entry(n, p->tabs, tw_by_L, false, true);
-            if (rc) { atsc_dplan_destroy(p); return fail(ctx, rc, "dplan_create: plan entry"); }
-            pi = p->tabs.by_n[n];
+        if (it == H.tabs.by_n.end()) {
+            int rc = build_plan_entry(n, H.tabs, tw_by_L, false, true);
+            if (rc) { *why = "dplan_create: plan entry"; return rc; }
+            pi = H.tabs.by_n[n];
         } else {
             pi = it->second;
         }
-        const DevPlan &dp = p->tabs.plans[pi];
+        const DevPlan &dp = H.tabs.plans[pi];
         const int c = class_of(n, dp.L);
-        if (c < 0) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_UNSUPPORTED, "dplan_create: frame class"); }
+        if (c < 0) { *why = "dplan_create: frame class"; return ATSC_E_UNSUPPORTED; }
         DevDFrame d;
-        d.payload_off = pos;
+        d.payload_off = pay;
         d.out_off = out_off;
         d.payload_len = (uint32_t)dl;
         d.n = n;
         d.tag = (uint32_t)tag;
         d.plan = pi;
-        frames.push_back(d);
-        cls.push_back(c);
-        p->class_count[c]++;
-        p->class_lds[c] = std::max(p->class_lds[c], dp.lds_bytes);
-        if (c == CLASS_LARGE) p->ws_stride = std::max(p->ws_stride, large_ws_bytes(n, dp.L, dp.kcap));
+        H.frames.push_back(d);
+        H.cls.push_back(c);
+        H.class_count[c]++;
+        H.class_lds[c] = std::max(H.class_lds[c], dp.lds_bytes);
+        if (c == CLASS_LARGE) H.ws_stride = std::max(H.ws_stride, large_ws_bytes(n, dp.L, dp.kcap));
         out_off += n;
-        pos += dl;
     }
-    if (frames.empty()) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_FORMAT, "dplan_create: no frames"); }
+    if (H.frames.empty()) { *why = "dplan_create: no frames"; return ATSC_E_FORMAT; }
+    H.n_samples = out_off;
+    return ATSC_OK;
+}
+// test hook of the sanitizer build (declared in atsc_internal.h, not part of the public ABI)
+extern "C" int atsc_internal_dplan_parse(const uint8_t *body, uint64_t body_len, int has_count,
+                                         uint64_t *n_frames, uint64_t *n_samples)
+{
+    ATSC_API_BEGIN
+    if (!body) return ATSC_E_INVALID;
+    DPlanHost H;
+    const char *why;
+    int rc = dplan_parse(body, body_len, has_count, H, &why);
+    if (rc) return rc;
+    if (n_frames) *n_frames = H.frames.size();
+    if (n_samples) *n_samples = H.n_samples;
+    return ATSC_OK;
+    ATSC_API_END
+}
+
+extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
+                                 int has_count, atsc_dplan **out)
+{
+    ATSC_API_BEGIN
+    if (!ctx || !body || !out) return fail(ctx, ATSC_E_INVALID, "dplan_create: null argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DPlanHost H;
+    {
+        const char *why;
+        int rc = dplan_parse(body, body_len, has_count, H, &why);
+        if (rc) return fail(ctx, rc, why);
+    }
+    atsc_dplan *p = new (std::nothrow) atsc_dplan();
+    if (!p) return ATSC_E_NOMEM;
+    p->ctx = ctx;
+    p->tabs = std::move(H.tabs);
+    p->class_count = H.class_count;
+    p->class_lds = H.class_lds;
+    p->class_first.assign(N_CLASSES, 0);
+    p->ws_stride = H.ws_stride;
+    std::vector<DevDFrame> &frames = H.frames;
+    std::vector<int> &cls = H.cls;
+    const uint64_t out_off = H.n_samples;
     p->n_frames = frames.size();
     p->n_samples = out_off;
     std::vector<uint32_t> ids(frames.size());
@@ -1305,11 +1347,13 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
 #undef PCHK
     *out = p;
     return ATSC_OK;
+    ATSC_API_END
 }
 
 extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t *d_body,
                                         double *d_out, void *stream)
 {
+    ATSC_API_BEGIN
     if (!ctx || !dp || !d_body || !d_out) return fail(ctx, ATSC_E_INVALID, "decompress: null argument");
     hipStream_t s = (hipStream_t)stream;
     for (int c = 0; c < N_CLASSES; ++c) {
@@ -1328,6 +1372,7 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_decompress", e);
     }
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // out == nullptr: *out_alloc receives a malloc'd buffer of exactly the decoded length (atsc_free)
@@ -1378,13 +1423,17 @@ done:
 extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
                                       int has_count, double *out, uint64_t out_cap, uint64_t *out_n)
 {
+    ATSC_API_BEGIN
     if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
     return decompress_frames_impl(ctx, body, body_len, has_count, out, out_cap, nullptr, out_n);
+    ATSC_API_END
 }
 extern "C" int atsc_decompress_frames_alloc(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
                                             int has_count, double **out, uint64_t *out_n)
 {
+    ATSC_API_BEGIN
     if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames_alloc: null argument");
     *out = nullptr;
     return decompress_frames_impl(ctx, body, body_len, has_count, nullptr, 0, out, out_n);
+    ATSC_API_END
 }

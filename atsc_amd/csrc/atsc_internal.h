@@ -1,6 +1,8 @@
 // Internal structures shared by the host glue and the HIP kernels.
 #pragma once
 #include <stdint.h>
+#include <new>
+#include <stdexcept>
 
 namespace atsc {
 
@@ -163,4 +165,58 @@ static inline uint32_t varint_len_u64(uint64_t v)
     return v < 251 ? 1u : v < (1ull << 16) ? 3u : v < (1ull << 32) ? 5u : 9u;
 }
 
+// No C++ exception may cross the C ABI (std::bad_alloc / std::length_error out of a container sized from
+// untrusted bytes would otherwise end the host process): every extern "C" body that can allocate sits
+// between these two.
+#define ATSC_API_BEGIN try {
+#define ATSC_API_END \
+    } catch (const std::bad_alloc &) { return ATSC_E_NOMEM; } \
+    catch (const std::length_error &) { return ATSC_E_NOMEM; } \
+    catch (...) { return ATSC_E_INVALID; }
+// One encoded frame record as it lies in a BRO body (frame/mod.rs:25-33):
+// varint(frame_size) varint(sample_count) varint(compressor) varint(len) payload[len].
+struct HostRecord {
+    uint64_t start;        // offset of the record's first byte
+    uint64_t payload_off;  // offset of the payload
+    uint64_t payload_len;  // <= UINT32_MAX, and the payload lies inside the body
+    uint64_t sample_count;
+    uint64_t tag;
+};
+// bincode varint; false on a truncated field or a marker byte above 253.  `pos` only
+// ever moves forward and stays <= len.
+static inline bool host_varint(const uint8_t *b, uint64_t len, uint64_t &pos, uint64_t &v)
+{
+    if (pos >= len) return false;
+    const uint8_t t = b[pos];
+    uint32_t nb;
+    if (t < 251) { v = t; pos += 1; return true; }
+    if (t == 251) nb = 2;
+    else if (t == 252) nb = 4;
+    else if (t == 253) nb = 8;
+    else return false;
+    if (len - pos < 1ull + nb) return false;
+    v = 0;
+    for (uint32_t i = 0; i < nb; ++i) v |= (uint64_t)b[pos + 1 + i] << (8 * i);
+    pos += 1 + nb;
+    return true;
+}
+// Reads the record at `pos` of untrusted bytes and moves `pos` behind it.  Every bound is checked in the
+// overflow-free form (a length field of 2^64 - k must not wrap `pos + len`).
+static inline bool host_next_record(const uint8_t *b, uint64_t len, uint64_t &pos, HostRecord &r)
+{
+    uint64_t fs, p = pos;
+    r.start = pos;
+    if (!host_varint(b, len, p, fs) || !host_varint(b, len, p, r.sample_count) ||
+        !host_varint(b, len, p, r.tag) || !host_varint(b, len, p, r.payload_len))
+        return false;
+    if (r.payload_len > len - p || r.payload_len > 0xFFFFFFFFull) return false;
+    r.payload_off = p;
+    pos = p + r.payload_len;
+    return true;
+}
+
 }  // namespace atsc
+
+// test hook (tests/asan): the host half of atsc_dplan_create on untrusted bytes, no GPU needed
+extern "C" int atsc_internal_dplan_parse(const uint8_t *body, uint64_t body_len, int has_count,
+                                         uint64_t *n_frames, uint64_t *n_samples);

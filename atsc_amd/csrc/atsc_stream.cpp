@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/atsc_hip.h"
+#include "atsc_internal.h"
 
 namespace {
 
@@ -96,17 +97,23 @@ static int queue_chunk(atsc_stream *s, const double *chunk, uint64_t n, int comp
 }
 extern "C" int atsc_stream_compress_chunk(atsc_stream *s, const double *chunk, uint64_t n)
 {
+    ATSC_API_BEGIN
     return queue_chunk(s, chunk, n, ATSC_NOOP, 0, 0.0f, 0);
+    ATSC_API_END
 }
 extern "C" int atsc_stream_compress_chunk_with(atsc_stream *s, const double *chunk, uint64_t n, int compressor)
 {
+    ATSC_API_BEGIN
     return queue_chunk(s, chunk, n, compressor, 0, 0.0f, 0);
+    ATSC_API_END
 }
 extern "C" int atsc_stream_compress_chunk_bounded_with(atsc_stream *s, const double *chunk, uint64_t n,
                                                        int compressor, float max_error, int compression_speed)
 {
+    ATSC_API_BEGIN
     // data.rs:68-72: Auto -> compress_best, everything else -> compress_bounded
     return queue_chunk(s, chunk, n, compressor, 1, max_error, compression_speed);
+    ATSC_API_END
 }
 
 // Runs every queued chunk through the GPU, one batch per distinct (compressor, bounded, error, level).
@@ -154,6 +161,7 @@ static int flush(atsc_stream *s)
 
 extern "C" int atsc_stream_to_bytes(atsc_stream *s, uint8_t **out, uint64_t *len)
 {
+    ATSC_API_BEGIN
     if (!s || !out || !len) return ATSC_E_INVALID;
     int rc = flush(s);
     if (rc) return rc;
@@ -169,36 +177,59 @@ extern "C" int atsc_stream_to_bytes(atsc_stream *s, uint8_t **out, uint64_t *len
     *out = buf;
     *len = pos;
     return ATSC_OK;
+    ATSC_API_END
 }
 
 extern "C" int atsc_stream_from_bytes(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, atsc_stream **out)
 {
+    ATSC_API_BEGIN
     if (!ctx || !bro || !out) return ATSC_E_INVALID;
+    *out = nullptr;
     uint64_t pos = 0, nf = 0;
     int rc = atsc_bro_open(bro, len, &pos, &nf);
     if (rc) return rc;
-    atsc_stream *s = new (std::nothrow) atsc_stream();
+    if (nf > len / 4) return ATSC_E_FORMAT;  // untrusted count: every record takes at least 4 bytes
+    std::unique_ptr<atsc_stream> s(new (std::nothrow) atsc_stream());
     if (!s) return ATSC_E_NOMEM;
     s->ctx = ctx;
     for (uint64_t f = 0; f < nf; ++f) {
-        const uint64_t start = pos;
-        uint64_t fs, sc, tag, dl;
-        if (!get_varint(bro, len, pos, fs) || !get_varint(bro, len, pos, sc) || !get_varint(bro, len, pos, tag) ||
-            !get_varint(bro, len, pos, dl) || pos + dl > len) {
-            delete s;
-            return ATSC_E_FORMAT;  // bincode decode .unwrap() (data.rs:98)
-        }
-        pos += dl;
+        atsc::HostRecord hr;
+        if (!atsc::host_next_record(bro, len, pos, hr)) return ATSC_E_FORMAT;  // bincode decode .unwrap() (data.rs:98)
         Item it;
-        it.record.assign(bro + start, bro + pos);
+        it.record.assign(bro + hr.start, bro + pos);
         s->items.push_back(std::move(it));
     }
-    *out = s;
+    *out = s.release();
     return ATSC_OK;
+    ATSC_API_END
+}
+
+// CompressedStream::from_bytes (data.rs:89-103) as a dry run: header, version, frame count and the walk over
+// the records, nothing decoded.  Host only.
+extern "C" int atsc_bro_scan(const uint8_t *bro, uint64_t len, uint64_t *n_frames, uint64_t *n_samples)
+{
+    ATSC_API_BEGIN
+    if (!bro) return ATSC_E_INVALID;
+    uint64_t pos = 0, nf = 0, ns = 0;
+    int rc = atsc_bro_open(bro, len, &pos, &nf);
+    if (rc) return rc;
+    if (nf > len / 4) return ATSC_E_FORMAT;
+    for (uint64_t f = 0; f < nf; ++f) {
+        atsc::HostRecord hr;
+        if (!atsc::host_next_record(bro, len, pos, hr)) return ATSC_E_FORMAT;
+        if (hr.tag > 6 || hr.tag == ATSC_AUTO) return ATSC_E_FORMAT;
+        if (ns + hr.sample_count < ns) return ATSC_E_FORMAT;
+        ns += hr.sample_count;
+    }
+    if (n_frames) *n_frames = nf;
+    if (n_samples) *n_samples = ns;
+    return ATSC_OK;
+    ATSC_API_END
 }
 
 extern "C" int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!s || !out || !n) return ATSC_E_INVALID;
     int rc = flush(s);
     if (rc) return rc;
@@ -231,6 +262,7 @@ extern "C" int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n)
     *out = buf;
     *n = got;
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -239,6 +271,7 @@ extern "C" int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n)
 extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n, int compressor,
                                   uint8_t error_pct, int sample_level, uint8_t **bro, uint64_t *len)
 {
+    ATSC_API_BEGIN
     if (!ctx || (!data && n) || !bro || !len) return ATSC_E_INVALID;
     *bro = nullptr;
     *len = 0;
@@ -264,6 +297,10 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
     };
     bool dirty = false;
     std::thread scanner;
+    struct Joiner {  // an early return or an exception must not destroy a joinable thread (std::terminate)
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{scanner};
     const bool overlap = n >= (1u << 20);
     if (overlap) scanner = std::thread([&] { dirty = has_nonfinite(data, n); });
     else dirty = has_nonfinite(data, n);
@@ -319,10 +356,12 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
     return ATSC_OK;
     }
     return ATSC_E_INVALID;  // not reached: the second attempt has no scanner left to send it round again
+    ATSC_API_END
 }
 
 extern "C" int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t len, double **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!ctx || !bro || !out || !n) return ATSC_E_INVALID;
     *out = nullptr;
     *n = 0;
@@ -338,6 +377,7 @@ extern "C" int atsc_decompress_data(atsc_ctx *ctx, const uint8_t *bro, uint64_t 
     // as bincode's decode_from_slice does (data.rs:98); the output is sized by the decoder.
     (void)body_off;
     return atsc_decompress_frames_alloc(ctx, bro + 9, len - 9, 1, out, n);
+    ATSC_API_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -370,9 +410,13 @@ static int write_file(const char *path, const uint8_t *p, uint64_t len)
 //   n_chunks:u32, sample_count:u32, bitdepth:u8, pad[3]}]   -- relative offsets are from the field
 extern "C" int atsc_wbro_to_bytes(const double *data, uint64_t n, uint8_t **out, uint64_t *len)
 {
+    ATSC_API_BEGIN
     if ((!data && n) || !out || !len) return ATSC_E_INVALID;
     const uint64_t CH = 2048;  // MAX_CHUNK_SIZE, wavbrro.rs:24
     const uint64_t nch = (n + CH - 1) / CH;
+    // rkyv's relative offsets are i32 (and sample_count u32): an archive above 2 GiB cannot be expressed;
+    // the reference's serializer fails there as well
+    if (n > 0xFFFFFFFFull || 8 * n + 8 * nch + 16 > 0x7FFFFFFFull) return ATSC_E_UNSUPPORTED;
     const uint64_t total = 12 + 8 * n + 8 * nch + 16;
     uint8_t *buf = (uint8_t *)calloc(total, 1);
     if (!buf) return ATSC_E_NOMEM;
@@ -397,10 +441,12 @@ extern "C" int atsc_wbro_to_bytes(const double *data, uint64_t n, uint8_t **out,
     *out = buf;
     *len = total;
     return ATSC_OK;
+    ATSC_API_END
 }
 
 extern "C" int atsc_wbro_from_bytes(const uint8_t *file, uint64_t len, double **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!file || !out || !n) return ATSC_E_INVALID;
     if (len < 12 + 16 || memcmp(file, "WBRO", 4) != 0 || memcmp(file + 8, "WBRO", 4) != 0)
         return ATSC_E_FORMAT;  // read.rs:23-29 -> Error::FormatError
@@ -431,16 +477,20 @@ extern "C" int atsc_wbro_from_bytes(const uint8_t *file, uint64_t len, double **
     *out = buf;
     *n = k;
     return ATSC_OK;
+    ATSC_API_END
 }
 extern "C" int atsc_wbro_read(const char *path, double **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     std::vector<uint8_t> buf;
     int rc = read_file(path, buf);
     if (rc) return rc;
     return atsc_wbro_from_bytes(buf.data(), buf.size(), out, n);
+    ATSC_API_END
 }
 extern "C" int atsc_wbro_write(const char *path, const double *data, uint64_t n)
 {
+    ATSC_API_BEGIN
     uint8_t *buf = nullptr;
     uint64_t len = 0;
     int rc = atsc_wbro_to_bytes(data, n, &buf, &len);
@@ -448,11 +498,13 @@ extern "C" int atsc_wbro_write(const char *path, const double *data, uint64_t n)
     rc = write_file(path, buf, len);
     free(buf);
     return rc;
+    ATSC_API_END
 }
 
 // utils/readers/bro_reader.rs:31-46: needs 12 readable bytes; a BRO file starts with "BRRO"
 extern "C" int atsc_bro_read_file(const char *path, uint8_t **out, uint64_t *len)
 {
+    ATSC_API_BEGIN
     if (!path || !out || !len) return ATSC_E_INVALID;
     *out = nullptr;
     *len = 0;
@@ -467,6 +519,7 @@ extern "C" int atsc_bro_read_file(const char *path, uint8_t **out, uint64_t *len
     *out = p;
     *len = buf.size();
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // Rust's `str::parse::<f64>` grammar: [+-]? ( "inf" | "infinity" | "nan" (any case) | digits [. digits?]
@@ -551,6 +604,7 @@ int read_lines(const char *path, std::vector<std::string> &lines)
 extern "C" int atsc_csv_read(const char *path, int has_header, const char *time_field, const char *value_field,
                              double **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!path || !out || !n) return ATSC_E_INVALID;
     std::vector<uint8_t> buf;
     int rc = read_file(path, buf);
@@ -594,4 +648,5 @@ extern "C" int atsc_csv_read(const char *path, int has_header, const char *time_
     *out = p;
     *n = vals.size();
     return ATSC_OK;
+    ATSC_API_END
 }

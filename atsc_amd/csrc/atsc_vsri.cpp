@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/atsc_hip.h"
+#include "atsc_internal.h"
 
 namespace atsc_text {
 bool parse_rust_f64(const std::string &s, double &v);                     // atsc_stream.cpp
@@ -180,6 +181,7 @@ extern "C" int32_t atsc_vsri_get_sample_count(const atsc_vsri *v) { return v ? s
 // Vsri::update_for_point (lib.rs:236-273)
 extern "C" int atsc_vsri_update_for_point(atsc_vsri *v, int32_t y)
 {
+    ATSC_API_BEGIN
     if (!v) return ATSC_E_INVALID;
     if (y < v->max_ts) return ATSC_E_INVALID;  // Error::UpdateIndexForPointError: a point in the past
     v->max_ts = y;
@@ -204,6 +206,7 @@ extern "C" int atsc_vsri_update_for_point(atsc_vsri *v, int32_t y)
     const Seg cur = last;
     v->seg.push_back(Seg{{0, wadd(cur.v[1], cur.v[3]), y, 1}});  // create_fake_segment (lib.rs:380-386)
     return ATSC_OK;
+    ATSC_API_END
 }
 
 extern "C" int atsc_vsri_get_sample(const atsc_vsri *v, int32_t y, int32_t *out)
@@ -275,6 +278,7 @@ extern "C" int atsc_vsri_is_empty(const atsc_vsri *v, int32_t t0, int32_t t1)
 // Vsri::get_all_timestamps (lib.rs:344-353)
 extern "C" int atsc_vsri_get_all_timestamps(const atsc_vsri *v, int32_t **out, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!v || !out || !n) return ATSC_E_INVALID;
     std::vector<int32_t> t;
     for (const Seg &s : v->seg)
@@ -285,11 +289,13 @@ extern "C" int atsc_vsri_get_all_timestamps(const atsc_vsri *v, int32_t **out, u
     *out = p;
     *n = t.size();
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // Vsri::flush_to (lib.rs:424-443): min, max, then one "m,x0,y0,count" line per segment
 extern "C" int atsc_vsri_flush_to(const atsc_vsri *v, const char *path)
 {
+    ATSC_API_BEGIN
     if (!v || !path) return ATSC_E_INVALID;
     FILE *f = fopen(path, "wb");
     if (!f) return ATSC_E_IO;
@@ -297,11 +303,13 @@ extern "C" int atsc_vsri_flush_to(const atsc_vsri *v, const char *path)
     for (const Seg &s : v->seg) ok = ok && fprintf(f, "%d,%d,%d,%d\n", s.v[0], s.v[1], s.v[2], s.v[3]) > 0;
     ok = (fclose(f) == 0) && ok;
     return ok ? ATSC_OK : ATSC_E_IO;
+    ATSC_API_END
 }
 // Vsri::load (lib.rs:447-486); malformed numbers or a segment without exactly 4 fields are unwrap
 // panics there, ATSC_E_FORMAT here
 extern "C" int atsc_vsri_load(const char *path, atsc_vsri **out)
 {
+    ATSC_API_BEGIN
     if (!path || !out) return ATSC_E_INVALID;
     *out = nullptr;
     std::vector<std::string> lines;
@@ -333,6 +341,7 @@ extern "C" int atsc_vsri_load(const char *path, atsc_vsri **out)
     }
     *out = v;
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // vsri::day_elapsed_seconds (lib.rs:49-57): seconds since midnight UTC of a unix timestamp.
@@ -352,6 +361,7 @@ extern "C" int atsc_day_elapsed_seconds(int64_t timestamp_sec, int32_t *out)
 // Sample { timestamp: i64, value: f64 } by header name.
 extern "C" int atsc_samples_csv_read(const char *path, int64_t **ts, double **val, uint64_t *n)
 {
+    ATSC_API_BEGIN
     if (!path || !ts || !val || !n) return ATSC_E_INVALID;
     *ts = nullptr;
     *val = nullptr;
@@ -395,11 +405,13 @@ extern "C" int atsc_samples_csv_read(const char *path, int64_t **ts, double **va
     *val = pv;
     *n = tv.size();
     return ATSC_OK;
+    ATSC_API_END
 }
 
 // csv-compressor/src/csv.rs:48-56: header from the struct's field names, itoa / ryu numbers, "\n"
 extern "C" int atsc_samples_csv_write(const char *path, const int64_t *ts, const double *val, uint64_t n)
 {
+    ATSC_API_BEGIN
     if (!path || (n && (!ts || !val))) return ATSC_E_INVALID;
     FILE *f = fopen(path, "wb");
     if (!f) return ATSC_E_IO;
@@ -411,12 +423,14 @@ extern "C" int atsc_samples_csv_write(const char *path, const int64_t *ts, const
     }
     ok = (fclose(f) == 0) && ok;
     return ok ? ATSC_OK : ATSC_E_IO;
+    ATSC_API_END
 }
 
 // Metric::append_samples (metric.rs:53-65), index part: every sample's millisecond timestamp becomes
 // seconds since midnight and extends the index; the values go to the WavBrro unchanged.
 extern "C" int atsc_metric_index_samples(atsc_vsri *index, const int64_t *ts_ms, uint64_t n, uint64_t *failed_at)
 {
+    ATSC_API_BEGIN
     if (!index || (n && !ts_ms)) return ATSC_E_INVALID;
     for (uint64_t i = 0; i < n; ++i) {
         int32_t sec;
@@ -428,11 +442,13 @@ extern "C" int atsc_metric_index_samples(atsc_vsri *index, const int64_t *ts_ms,
         }
     }
     return ATSC_OK;
+    ATSC_API_END
 }
 // Metric::get_samples (metric.rs:83-97): timestamp of sample i = index.get_time(i); None is an
 // unwrap panic there
 extern "C" int atsc_metric_sample_times(const atsc_vsri *index, uint64_t n, int64_t *out)
 {
+    ATSC_API_BEGIN
     if (!index || (n && !out)) return ATSC_E_INVALID;
     for (uint64_t i = 0; i < n; ++i) {
         int32_t t;
@@ -442,4 +458,5 @@ extern "C" int atsc_metric_sample_times(const atsc_vsri *index, uint64_t n, int6
         out[i] = (int64_t)t;
     }
     return ATSC_OK;
+    ATSC_API_END
 }

@@ -255,6 +255,11 @@ uint64_t atsc_bro_prefix(uint64_t n_frames, uint8_t *out);
  * and version; returns the offset of the first frame record (after the count varint) and
  * the frame count, or ATSC_E_FORMAT / ATSC_E_VERSION. */
 int atsc_bro_open(const uint8_t *bro, uint64_t len, uint64_t *body_off, uint64_t *n_frames);
+/* CompressedStream::from_bytes as a dry run (data.rs:89-103): header, version, frame count and the
+ * walk over every frame record (frame/mod.rs:25-33) without decoding a payload.  ATSC_E_FORMAT where
+ * the reference's bincode decode `.unwrap()` panics (data.rs:98): a truncated or inflated length, a
+ * count the bytes cannot hold, an unknown compressor id.  Outputs may be NULL. */
+int atsc_bro_scan(const uint8_t *bro, uint64_t len, uint64_t *n_frames, uint64_t *n_samples);
 
 /* ------------------------------------------------------------------------------------------
  * csv-compressor front end: host-only, no GPU context needed.
