@@ -65,6 +65,9 @@ SIGNATURES = {
     "atsc_ctx_profile_read": (C.c_int, [_vp, _f64p, _u64p]),
     "atsc_compress_frames": (C.c_int, [_vp, _f64p, _u64p, C.c_uint64, C.c_int, C.c_int, C.c_float,
                                        C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u8p, _f64p]),
+    "atsc_shard_range": (None, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
+    "atsc_compress_frames_sharded": (C.c_int, [C.POINTER(_vp), C.c_uint32, _f64p, _u64p, C.c_uint64, C.c_int, C.c_int,
+                                               C.c_float, C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u8p, _f64p]),
     "atsc_dplan_create": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, C.POINTER(_vp)]),
     "atsc_dplan_destroy": (None, [_vp]),
     "atsc_dplan_n_frames": (C.c_uint64, [_vp]),

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -1111,6 +1113,91 @@ done:
     pool_free(ctx, d_err);
     atsc_plan_destroy(plan);
     return rc;
+    ATSC_API_END
+}
+
+// Frames are independent (main.rs:146-163), so a batch shards over devices by contiguous frame ranges:
+// the same split for every host language (atsc_amd/parallel.py::shard_range is this function).
+extern "C" void atsc_shard_range(uint64_t n_units, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end)
+{
+    if (world == 0) world = 1;
+    const uint64_t base = n_units / world, rem = n_units % world;
+    const uint64_t b = (uint64_t)rank * base + std::min<uint64_t>(rank, rem);
+    if (begin) *begin = b;
+    if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
+
+// One process, several GPUs: shard r = atsc_shard_range(n_frames, r, n_ctx) goes through ctxs[r] on a
+// host thread of its own (a context is used by one thread at a time); the shards' records are laid end to
+// end in frame order.  The result is byte for byte what one context returns for the whole batch.
+extern "C" int atsc_compress_frames_sharded(atsc_ctx *const *ctxs, uint32_t n_ctx, const double *samples,
+                                            const uint64_t *frame_off, uint64_t n_frames, int compressor,
+                                            int bounded, float max_error, int sample_level, uint8_t *body,
+                                            uint64_t body_cap, uint64_t *body_len, uint64_t *rec_off,
+                                            uint8_t *chosen, double *err)
+{
+    ATSC_API_BEGIN
+    if (!ctxs || n_ctx == 0 || !samples || !frame_off || !body || !body_len || n_frames == 0) return ATSC_E_INVALID;
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (!ctxs[r]) return ATSC_E_INVALID;
+    if (n_ctx == 1)
+        return atsc_compress_frames(ctxs[0], samples, frame_off, n_frames, compressor, bounded, max_error,
+                                    sample_level, body, body_cap, body_len, rec_off, chosen, err);
+    struct Shard {
+        uint64_t b = 0, e = 0, len = 0;
+        std::unique_ptr<uint8_t[]> buf;
+        std::vector<uint64_t> off;
+        int rc = ATSC_OK;
+    };
+    std::vector<Shard> sh(n_ctx);
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        atsc_shard_range(n_frames, r, n_ctx, &sh[r].b, &sh[r].e);
+        const uint64_t nf = sh[r].e - sh[r].b;
+        if (!nf) continue;
+        uint64_t cap = 0;
+        for (uint64_t f = sh[r].b; f < sh[r].e; ++f)
+            cap += atsc_payload_bound_bytes(frame_off[f + 1] - frame_off[f]) + 16;
+        sh[r].buf.reset(new uint8_t[cap ? cap : 1]);  // worst case; only the bytes produced are touched
+        sh[r].len = cap;
+        sh[r].off.resize(nf + 1);
+    }
+    {
+        std::vector<std::thread> th;
+        struct JoinAll {
+            std::vector<std::thread> &t;
+            ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); }
+        } join_all{th};
+        for (uint32_t r = 0; r < n_ctx; ++r) {
+            Shard *S = &sh[r];
+            if (S->e == S->b) continue;
+            atsc_ctx *c = ctxs[r];
+            th.emplace_back([=] {
+                uint64_t blen = 0;
+                S->rc = atsc_compress_frames(c, samples, frame_off + S->b, S->e - S->b, compressor, bounded,
+                                             max_error, sample_level, S->buf.get(), S->len, &blen, S->off.data(),
+                                             chosen ? chosen + S->b : nullptr, err ? err + S->b : nullptr);
+                S->len = blen;
+            });
+        }
+    }
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        if (sh[r].e == sh[r].b) continue;
+        if (sh[r].rc) return sh[r].rc;
+        total += sh[r].len;
+    }
+    *body_len = total;
+    if (total > body_cap) return ATSC_E_CAPACITY;
+    uint64_t pos = 0;
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        if (sh[r].e == sh[r].b) continue;
+        memcpy(body + pos, sh[r].buf.get(), sh[r].len);
+        if (rec_off)
+            for (uint64_t f = sh[r].b; f < sh[r].e; ++f) rec_off[f] = pos + sh[r].off[f - sh[r].b];
+        pos += sh[r].len;
+    }
+    if (rec_off) rec_off[n_frames] = total;
+    return ATSC_OK;
     ATSC_API_END
 }
 

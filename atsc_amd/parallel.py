@@ -44,12 +44,14 @@ class PipelinedGather:
     """Steady-state gather for a loop that produces one record buffer per step on every rank.
 
     Segment capacity is agreed once (max over ranks of the observed size, plus slack); after that
-    every step issues ONE asynchronous `gather` of `cap` bytes per rank, with no host synchronisation:
-    the byte count of the step rides in the last 8 bytes of the segment (a device-side copy into the
-    record buffer, which is far larger than `cap`), so the collective count per step is one and the
-    communicator's stream keeps up with the codecs.  The producer moves on to the other buffer set
-    (depth 2).  Rank 0 ends up with `world` segments at stride `cap`: the encoded stream is the
-    concatenation of segment r's first size_r bytes, in rank order = frame order."""
+    every step issues ONE asynchronous `gather` of `cap` bytes per rank, with no host synchronisation.
+    Each rank stages its records in a segment of its own whose last 8 bytes carry the step's byte
+    count (the record buffer itself is never written to), so the collective count per step is one and
+    the communicator's stream keeps up with the codecs.  A step whose records do not fit the agreed
+    capacity is not truncated silently: the sending rank raises a sticky device-side flag,
+    `overflowed()` (a collective) reports it on every rank, and the caller repeats that exchange with
+    `gather_records`, which has no capacity.  Rank 0 ends up with `world` segments at stride `cap`: the
+    encoded stream is the concatenation of segment r's first size_r bytes, in rank order = frame order."""
 
     TAIL = 8  # bytes at the end of every segment that carry the step's byte count (int64)
 
@@ -58,32 +60,50 @@ class PipelinedGather:
         t = torch.tensor([int(observed_bytes)], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         self.cap = (int(int(t.item()) * slack) + 4096 + self.TAIL + 15) & ~15
+        self.room = self.cap - self.TAIL  # record bytes a segment can carry
         self.seg = [None] * depth
         self.work = [None] * depth
+        self.stage = [torch.empty(self.cap, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.over = torch.zeros(1, dtype=torch.int64, device=device)  # sticky: some step did not fit
         if rank == 0:
             for d in range(depth):
                 self.seg[d] = [torch.empty(self.cap, dtype=torch.uint8, device=device) for _ in range(world)]
 
     def before_produce(self, slot):
-        """Call before overwriting buffer set `slot`: waits for the gather that last read it."""
+        """Call before reusing slot `slot`: waits for the gather that last read its staging segment."""
         if self.work[slot] is not None:
             self.work[slot].wait()
             self.work[slot] = None
 
     def submit(self, slot, body, nbytes_tensor):
-        """body: this rank's uint8 buffer (>= cap bytes, 8-byte aligned); nbytes_tensor: int64[1] on
-        the same device.  The records must end before cap - TAIL (checked by `result`)."""
-        tail = body[self.cap - self.TAIL: self.cap].view(self.torch.int64)
-        tail.copy_(nbytes_tensor.reshape(1))
-        self.work[slot] = self.dist.gather(body[: self.cap], gather_list=self.seg[slot] if self.rank == 0 else None,
+        """body: this rank's uint8 record buffer; nbytes_tensor: int64[1] on the same device (the number
+        of record bytes in it).  Everything is enqueued on the current stream; nothing blocks the host."""
+        torch = self.torch
+        st = self.stage[slot]
+        k = min(self.room, body.numel())
+        st[:k].copy_(body[:k])  # bytes beyond the step's size are never read by anybody
+        nb = nbytes_tensor.reshape(1).to(torch.int64)
+        st[self.room:].view(torch.int64).copy_(nb)
+        self.over.copy_(torch.maximum(self.over, (nb > self.room).to(torch.int64)))
+        self.work[slot] = self.dist.gather(st, gather_list=self.seg[slot] if self.rank == 0 else None,
                                            dst=0, async_op=True)
 
     def drain(self):
         for slot in range(self.depth):
             self.before_produce(slot)
 
+    def overflowed(self):
+        """Collective: True on every rank if any rank's records outgrew the agreed capacity in any step
+        since the last call (those steps' segments are truncated and must not be used)."""
+        t = self.over.clone()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.over.zero_()
+        return bool(int(t.item()))
+
     def result(self, slot):
         """(rank 0, after drain) -> list of byte views in rank order, and their sizes."""
-        sizes = [int(self.seg[slot][r][self.cap - self.TAIL:].view(self.torch.int64).item()) for r in range(self.world)]
-        assert all(0 <= s <= self.cap - self.TAIL for s in sizes), "a segment outgrew the agreed capacity"
+        sizes = [int(self.seg[slot][r][self.room:].view(self.torch.int64).item()) for r in range(self.world)]
+        if not all(0 <= s <= self.room for s in sizes):
+            raise RuntimeError("a segment outgrew the agreed capacity (%r > %d): repeat the exchange with "
+                               "gather_records" % (sizes, self.room))
         return [self.seg[slot][r][: sizes[r]] for r in range(self.world)], sizes

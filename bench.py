@@ -2,14 +2,16 @@
 """bench.py -- headline benchmark of the MI355X-native ATSC compressor path.
 
 Metric (BASELINE.json): Msamples/sec compressed (auto, e=5%) + ratio.
-Workload at every N: BASELINE.json configs[2] per GPU -- 10,485,760 synthetic f64 samples in
-40960 frames of 256 (classes C0..C4 cycled per 65536-sample block, series id =
-rank), `--compressor auto`, max_error = (float)5/100.  One "step" = one pass of the hot path
-(per-frame FFT / Catmull-Rom / RLE / Constant fit + error check + selector + BRO record packing)
-over that batch with the samples already resident in HBM.  N > 1: one process per GPU
-(torch.distributed, backend nccl = RCCL); frames shard by rank with no data-path collective;
-the only exchange is the gather of the encoded records to rank 0 (sizes all-gather + P2P),
-which is inside the timed region.  Scaling is weak (per-GPU work fixed).
+Workload at N = 1: BASELINE.json configs[2] -- 10,485,760 synthetic f64 samples in 40960 frames of 256
+(classes C0..C4 cycled per 65536-sample block), `--compressor auto`, max_error =
+(float)5/100; four different series are resident and the timed loop rotates over them.  One "step" =
+one pass of the hot path (per-frame FFT / Catmull-Rom / RLE / Constant fit + error check + selector +
+BRO record packing) over one batch with the samples already resident in HBM.
+N > 1: BASELINE.json configs[3] -- 4096 series x 262,144 samples (2^30), auto e=1%, series sharded
+contiguously over the ranks (4096 / N each: total work fixed, "strong"), one process per GPU
+(torch.distributed, backend nccl = RCCL), no data-path collective; the only exchange is the gather of the
+encoded records to rank 0, inside the timed region and overlapped with the next step's codecs.
+`--workload config3` runs the same workload on one GPU (the curve's 1-GPU point).
 
 Prints ONE JSON line on rank 0.
 """
@@ -118,12 +120,103 @@ def cpu_baseline(x, off, me, frames_per_block=256, blocks=160):
     }
 
 
+def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
+    """Host buffer -> host BRO bytes and back through the host-pointer entry points (PCIe inclusive;
+    SURVEY.md 8(d) asks for it next to the device-resident figure).  Never `value`."""
+    import ctypes as C
+
+    lib = atsc_amd.capi.lib()
+    n = len(x)
+    out = {}
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return r, float(np.median(ts))
+
+    # atsc_compress_frames, F256 framing (what INTEGRATION.md's Rust binding calls)
+    nf = len(off) - 1
+    cap = int(nf * (32 + 14 * FRAME + 16))
+    body = np.empty(cap, dtype=np.uint8)
+    blen = C.c_uint64()
+    offc = np.ascontiguousarray(off, dtype=np.uint64)
+
+    def cf():
+        rc = lib.atsc_compress_frames(ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)),
+                                      offc.ctypes.data_as(C.POINTER(C.c_uint64)), nf, atsc_amd.AUTO, 1,
+                                      C.c_float(np.float32(me)), 0, body.ctypes.data_as(C.POINTER(C.c_uint8)), cap,
+                                      C.byref(blen), None, None, None)
+        atsc_amd.capi.check(rc, ctx._h)
+        return blen.value
+
+    nbytes, dt = timed(cf)
+    out["compress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "bytes": nbytes}
+    rec = bytes(body[:nbytes])
+    recarr = np.frombuffer(rec, dtype=np.uint8)
+    dec = np.empty(n, dtype=np.float64)
+    on = C.c_uint64()
+
+    def df():
+        rc = lib.atsc_decompress_frames(ctx._h, recarr.ctypes.data_as(C.POINTER(C.c_uint8)), len(rec), 0,
+                                        dec.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(on))
+        atsc_amd.capi.check(rc, ctx._h)
+        return on.value
+
+    got, dt = timed(df)
+    assert got == n
+    out["decompress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
+    # atsc_compress_data / atsc_decompress_data: the atsc CLI's calls, reference chunker framing (80 x 131072)
+    bro = C.POINTER(C.c_uint8)()
+    ln = C.c_uint64()
+
+    def cd():
+        rc = lib.atsc_compress_data(ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)), n, atsc_amd.AUTO, ERROR_PCT, 0,
+                                    C.byref(bro), C.byref(ln))
+        atsc_amd.capi.check(rc, ctx._h)
+        b = bytes(C.cast(bro, C.POINTER(C.c_uint8 * ln.value)).contents)
+        lib.atsc_free(bro)
+        return b
+
+    bro_bytes, dt = timed(cd)
+    out["compress_data_chunker"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "bytes": len(bro_bytes)}
+    broarr = np.frombuffer(bro_bytes, dtype=np.uint8)
+    outp = C.POINTER(C.c_double)()
+    cnt = C.c_uint64()
+
+    def dd():
+        rc = lib.atsc_decompress_data(ctx._h, broarr.ctypes.data_as(C.POINTER(C.c_uint8)), len(bro_bytes),
+                                      C.byref(outp), C.byref(cnt))
+        atsc_amd.capi.check(rc, ctx._h)
+        lib.atsc_free(outp)
+        return cnt.value
+
+    got, dt = timed(dd)
+    assert got == n
+    out["decompress_data_chunker"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
+    out["note"] = "host buffer -> host buffer, PCIe inclusive, median of %d calls; pageable caller memory" % reps
+    return out
+
+
+ROTATE = 4          # resident batches the timed loop cycles through (N = 1 workload)
+C3_SERIES = 4096    # configs[3]: 4096 series x 262144 samples = 2^30
+C3_PER = 262144
+C3_ERROR_PCT = 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--workload", choices=["auto", "config2", "config3"], default="auto",
+                    help="auto: configs[2] at N = 1 (the metric's config), configs[3]'s per-rank share at N > 1")
+    ap.add_argument("--series", type=int, default=C3_SERIES, help="config3 only: total series over all ranks")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
                          "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
@@ -149,10 +242,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -162,18 +257,47 @@ def main():
 
     G.build()
     import atsc_amd
+    from atsc_amd import parallel
     from tests import helpers as H
 
-    me = float(np.float32(ERROR_PCT) / np.float32(100))
-    x = H.synth_series(rank, N_SAMPLES)
-    off = H.frame_offsets(N_SAMPLES, FRAME)
+    workload = args.workload
+    if workload == "auto":
+        workload = "config2" if world == 1 else "config3"
     ctx = atsc_amd.Context(dev_index)
+    if workload == "config2":
+        # BASELINE.json configs[2]: one 10,485,760-sample series per batch, classes cycled per 65536-sample
+        # block.  ROTATE different series are resident and the timed loop walks through them, so a step never
+        # sees the batch whose costs ordered its launch: the hint is a prediction from another batch of the
+        # same layout, as in a service that gets the next window of the same series.
+        error_pct = ERROR_PCT
+        n_local = N_SAMPLES
+        xs = [H.synth_series(rank * ROTATE + b, N_SAMPLES) for b in range(ROTATE)]
+        d_xs = [torch.from_numpy(v).to(dev) for v in xs]
+        units_total = world * N_SAMPLES
+        desc = ("BASELINE.json configs[2] per GPU: 10,485,760 f64 samples, 40960 frames x 256, --compressor auto, "
+                "e=5%% (max_error=(float)5/100), classes C0-C4 cycled per 65536-sample block, inputs resident in "
+                "HBM; the timed loop rotates over %d different resident batches (series ids %d..%d)"
+                % (ROTATE, rank * ROTATE, rank * ROTATE + ROTATE - 1))
+    else:
+        # BASELINE.json configs[3]: 4096 series x 262,144 samples (2^30), class = series % 5, auto e=1%,
+        # series s on rank s / (4096 / N): total work fixed, per-rank share 4096 / N series.
+        error_pct = C3_ERROR_PCT
+        sb, se = parallel.shard_range(args.series, rank, world)
+        n_local = (se - sb) * C3_PER
+        d_x = torch.empty(n_local, dtype=torch.float64, device=dev)
+        for s in range(sb, se):
+            d_x[(s - sb) * C3_PER:(s - sb + 1) * C3_PER] = H.synth_series_torch(torch, dev, s, C3_PER, s % 5)
+        d_xs = [d_x]
+        xs = None
+        units_total = args.series * C3_PER
+        desc = ("BASELINE.json configs[3]: %d series x 262,144 f64 samples (%d samples over all ranks), "
+                "class = series %% 5, --compressor auto, e=1%% (max_error=(float)1/100), 256-sample frames, series "
+                "sharded contiguously by rank (%d per rank), inputs resident in HBM, encoded records gathered to "
+                "rank 0 every step" % (args.series, units_total, se - sb))
+    me = float(np.float32(error_pct) / np.float32(100))
+    off = np.arange(0, n_local + 1, FRAME, dtype=np.uint64)
     plan = ctx.plan(off)
-    d_x = torch.from_numpy(x).to(dev)
-    outs = plan.alloc_outputs(torch, dev)
     stream = torch.cuda.current_stream().cuda_stream
-
-    from atsc_amd import parallel
 
     # Steady state of a compression service: batch after batch.  Two output sets; the record packing
     # of step i runs on the context's pack stream and overlaps the frame codecs of step i+1 (and, for
@@ -181,26 +305,27 @@ def main():
     pipelined = not args.no_pipeline
     if args.no_adaptive_order:
         ctx.set_adaptive_order(False)
-    outs2 = [outs, plan.alloc_outputs(torch, dev)]
+    outs2 = [plan.alloc_outputs(torch, dev), plan.alloc_outputs(torch, dev)]
     pg = None
     gstream = torch.cuda.Stream(device=dev) if world > 1 else None
+    R = len(d_xs)
 
-    def step(i):
+    def step(i, pipe=pipelined):
         o = outs2[i % 2]
         if pg is not None:
             pg.before_produce(i % 2)
-        plan.compress(d_x, o, atsc_amd.AUTO, True, me, 0, stream, pipelined=pipelined)
+        plan.compress(d_xs[i % R], o, atsc_amd.AUTO, True, me, 0, stream, pipelined=pipe)
         if world > 1:
             # the path's only exchange: the encoded records go to rank 0
             if pg is not None:
-                if pipelined:
+                if pipe:
                     plan.join(gstream.cuda_stream)
                     with torch.cuda.stream(gstream):
                         pg.submit(i % 2, o["body"], o["rec_off"][-1:])
                 else:
                     pg.submit(i % 2, o["body"], o["rec_off"][-1:])
                 return
-            if pipelined:
+            if pipe:
                 plan.join(stream)
             if share:  # rehearsal on one GPU: gloo moves host tensors
                 nb = int(o["rec_off"][-1].item())
@@ -208,9 +333,43 @@ def main():
             else:
                 parallel.gather_records(dist, torch, o["body"], o["rec_off"][-1:], rank, world)
 
+    def timed_loop(steps, pipe):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, pipe)
+        if pipe:
+            plan.join(stream)
+        if pg is not None:
+            pg.drain()
+        torch.cuda.synchronize()  # device-wide: codec, pack and communicator streams
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # encoded bytes of every resident batch (untimed): the ratio and the algorithmic bytes are averages over them
+    body_bytes_b = []
+    for b in range(R):
+        plan.compress(d_xs[b], outs2[0], atsc_amd.AUTO, True, me, 0, stream, pipelined=False)
+        torch.cuda.synchronize()
+        body_bytes_b.append(int(outs2[0]["rec_off"][-1].item()))
+    chosen = outs2[0]["chosen"].cpu().numpy()
     for i in range(max(args.warmup, 1 if world > 1 else 0)):
         step(i)
+    if pipelined:
+        plan.join(stream)
     torch.cuda.synchronize()
+    gather_mode = None
+    if world > 1:
+        gather_mode = "size all-gather + point-to-point sends (gather_records)"
     if world > 1 and not share:
         # segment capacity agreed once from the warm-up result; no host sync inside the timed loop.
         # One untimed trial step validates the asynchronous gather on this backend; any exception
@@ -218,10 +377,12 @@ def main():
         # the flag is agreed by an all-reduce).
         ok = 1
         try:
-            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, int(outs2[0]["rec_off"][-1].item()))
+            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, max(body_bytes_b))
             step(0)
             pg.drain()
             torch.cuda.synchronize()
+            if pg.overflowed():
+                raise RuntimeError("trial step outgrew the agreed segment capacity")
         except Exception as e:  # pragma: no cover - depends on the communication backend
             sys.stderr.write("pipelined gather unavailable (%r); using the simple gather\n" % (e,))
             ok = 0
@@ -229,59 +390,50 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             pg = None
+        else:
+            gather_mode = "one asynchronous fixed-capacity gather per step (PipelinedGather), overlapped with the next step's codecs"
     ctx.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if pipelined:
-        plan.join(stream)
+    dt = timed_loop(args.steps, pipelined)
+    gathered_sizes = None
     if pg is not None:
-        pg.drain()
-    torch.cuda.synchronize()  # device-wide: codec, pack and communicator streams
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if pg is not None and rank == 0:
-        segs, sizes = pg.result((args.steps - 1) % 2)
-        assert len(segs) == world and sizes[0] == int(outs2[(args.steps - 1) % 2]["rec_off"][-1].item())
+        if pg.overflowed():
+            raise SystemExit("a timed step's records outgrew the gather capacity: the run is void")
+        if rank == 0:
+            segs, gathered_sizes = pg.result((args.steps - 1) % 2)
+            assert len(segs) == world and gathered_sizes[0] == body_bytes_b[(args.steps - 1) % R]
     kern_ms, launches = ctx.profile_read()
     ctx.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The same steps through plain single-stream calls (atsc_compress_plan_dev: codecs, then the packing, on
+    # one stream, frames in index order, no cost hint), same rotation of batches.
+    value_no_hint = None
+    if world == 1:
+        for i in range(2):
+            step(i, False)
+        torch.cuda.synchronize()
+        dt_plain = timed_loop(args.steps, False)
+        value_no_hint = units_total * args.steps / dt_plain / 1e6
 
-    body_bytes = int(outs["rec_off"][-1].item())
+    body_bytes = float(np.mean(body_bytes_b))
     if world > 1:
-        t = torch.tensor([body_bytes], dtype=torch.int64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_body = int(t.item())
+        t = torch.tensor([body_bytes_b[0]], dtype=torch.int64, device="cpu" if share else dev)
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(lst, t)
+        per_rank_bytes = [int(v.item()) for v in lst]
+        total_body = float(sum(per_rank_bytes))
     else:
+        per_rank_bytes = [int(body_bytes_b[0])]
         total_body = body_bytes
 
     if rank == 0:
-        total_samples = N_SAMPLES * world
-        value = total_samples * args.steps / dt / 1e6
-        chosen = outs["chosen"].cpu().numpy()
+        value = units_total * args.steps / dt / 1e6
         codecs = {atsc_amd.capi.COMPRESSOR_NAMES[int(c)]: int(np.sum(chosen == c)) for c in np.unique(chosen)}
-        # roofline of the dominant kernel (k_compress<1,5>: every 256-sample frame of the batch).
+        # roofline of the dominant kernel (k_compress<1,5,false,256>: every 256-sample frame of the batch).
         # Algorithmic bytes per launch: 8 B read per input sample + encoded record bytes.
-        algo_bytes = 8.0 * N_SAMPLES + body_bytes
+        algo_bytes = 8.0 * n_local + body_bytes
         k_avg_ms = kern_ms / max(launches, 1)
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("k_compress_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": "Msamples/sec compressed (auto, e=5%)",
+            "metric": "Msamples/sec compressed (auto, e=%d%%)" % error_pct,
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -289,25 +441,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if workload == "config2" else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "ratio": 8.0 * total_samples / (total_body + 9 * world + 3 * world),
+            "ratio": 8.0 * units_total / (total_body + 12 * world) if workload == "config3"
+                     else 8.0 * n_local / (body_bytes + 12),
             "config": {
-                "workload": "BASELINE.json configs[2] per GPU: 10,485,760 f64 samples, 40960 frames x 256, "
-                            "--compressor auto, e=5% (max_error=(float)5/100), classes C0-C4 cycled per "
-                            "65536-sample block, inputs resident in HBM",
+                "workload": desc,
                 "frames_per_gpu": plan.n_frames,
                 "frame_len": FRAME,
                 "codecs_rank0": codecs,
-                "encoded_bytes_rank0": body_bytes,
-                "parallelism": "frames sharded by rank (%d), RCCL gather of records to rank 0" % world
+                "encoded_bytes_rank0": int(body_bytes),
+                "encoded_bytes_per_rank": per_rank_bytes,
+                "parallelism": ("frames sharded by rank over %d processes, backend %s (%d ranks in the group), records "
+                                "gathered to rank 0: %s" % (world, backend, dist.get_world_size(), gather_mode))
                                if world > 1 else "single GPU",
+                "gathered_bytes_last_step": gathered_sizes,
                 "pipeline": ("record packing of step i on the pack stream overlaps the codecs of step i+1 "
                              "(two scratch + output sets)" +
                              ("" if args.no_adaptive_order else "; within a launch the frames start costliest "
-                              "first, cost = shader clocks of the same frame slot two steps earlier"))
+                              "first, cost = shader clocks the same frame slot took two steps earlier (another batch)"))
                             if pipelined else "single stream",
             },
             "roofline": {
@@ -317,14 +471,30 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": None,
                 "kernel_ms_avg": k_avg_ms,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(x, off, me)
+        if value_no_hint is not None:
+            out["value_no_hint"] = value_no_hint
+        vmod = os.path.join(ROOT, "profiles", "valu_model.json")
+        if os.path.exists(vmod) and workload == "config2":
+            try:
+                vm = json.load(open(vmod))
+                floor_ms = float(vm["issue_floor_us_per_launch"]) * 1e-3
+                out["roofline_valu"] = {
+                    "bound": "valu issue", "kernel": "k_compress<1,5,false,256>",
+                    "floor_ms": floor_ms, "kernel_ms_avg": k_avg_ms, "frac": floor_ms / k_avg_ms if k_avg_ms > 0 else None,
+                    "source": "profiles/valu_model.json: " + vm.get("source", ""),
+                }
+            except Exception:
+                pass
+        if world == 1 and workload == "config2" and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(ctx, atsc_amd, xs[0], off, me)
+        if world == 1 and workload == "config2" and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(xs[0], off, me)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -168,6 +168,20 @@ int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *f
                          int sample_level, uint8_t *body, uint64_t body_cap, uint64_t *body_len,
                          uint64_t *rec_off, uint8_t *chosen, double *err);
 
+/* Several GPUs.  Frames are independent (the loop at main.rs:146-163 shares nothing between chunks), so a
+ * batch shards by contiguous frame ranges and the encoded stream is the shards' records laid end to
+ * end.  atsc_shard_range is the split every layer uses: unit ranges of sizes differing by at most one,
+ * rank order = frame order.  A multi-process host (one process and one atsc_ctx per GPU, as bench.py
+ * and atsc_amd/parallel.py run it) calls the single-context entry points on its own range and gathers
+ * the record bytes to rank 0.  A single-process host hands one context per device to
+ * atsc_compress_frames_sharded: each shard runs on its own host thread, and the outputs are byte for
+ * byte those of atsc_compress_frames on one context. */
+void atsc_shard_range(uint64_t n_units, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
+int atsc_compress_frames_sharded(atsc_ctx *const *ctxs, uint32_t n_ctx, const double *samples,
+                                 const uint64_t *frame_off, uint64_t n_frames, int compressor, int bounded,
+                                 float max_error, int sample_level, uint8_t *body, uint64_t body_cap,
+                                 uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen, double *err);
+
 /* ------------------------------------------------------------------------ */
 /* decompress: CompressedStream::decompress (data.rs:104-109) ->             */
 /*             CompressorFrame::decompress (frame/mod.rs:152-158)            */

@@ -171,6 +171,39 @@ def synth_series(series_id, n, klass=None, block=65536):
     return out
 
 
+def synth_series_torch(torch, device, series_id, n, klass):
+    """The same generator on the GPU for the billion-sample configs (bench.py, N > 1): classes 0-2 are
+    evaluated with torch on `device` (identical splitmix64 stream; sin() may differ from numpy's in the
+    last place, which no test depends on), classes 3 and 4 come from synth_series."""
+    if klass in (3, 4):
+        return torch.from_numpy(synth_series(series_id, n, klass=klass)).to(device)
+
+    def s64(v):  # two's-complement image of a u64 constant
+        v &= MASK64
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    seed = (0xA75C000000000000 + series_id) & MASK64
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device=device)
+    z = idx * s64(0x9E3779B97F4A7C15) + s64(seed)
+    z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    u = lsr(z, 11).to(torch.float64) * (2.0 ** -53)
+    i = torch.arange(n, dtype=torch.float64, device=device)
+    two_pi = 2.0 * math.pi
+    if klass == 0:
+        return (1000.0 + 200.0 * torch.sin(two_pi * i / 97.0) + 50.0 * torch.sin(two_pi * i / 1013.0 + 0.3)
+                + 5.0 * (u - 0.5))
+    if klass == 1:
+        return (1000.0 + 300.0 * torch.sin(two_pi * i / 41.0) + 200.0 * torch.sin(two_pi * i / 11.7)
+                + 100.0 * torch.sin(two_pi * i / 5.3) + 60.0 * torch.sin(two_pi * i / 2.9) + 20.0 * (u - 0.5))
+    ii = torch.arange(n, dtype=torch.int64, device=device)
+    return torch.floor(500.0 + ((ii // 64) % 400).to(torch.float64) + ((ii % 64) * 3).to(torch.float64) / 4.0)
+
+
 def frame_offsets(n, frame):
     offs = list(range(0, n, frame)) + [n]
     return np.array(offs, dtype=np.uint64)

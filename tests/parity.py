@@ -25,6 +25,13 @@ FFT_ERR_RTOL = 2e-6      # relative, for the large MAPE values of frames with ne
 POLY_ERR_RTOL = 1e-11    # summation order only
 BOUNDARY_EPS = 5e-6
 BOUNDARY_FRAC = 0.002
+# Frames in which two bins of (near-)equal norm were admitted in another order, or another one of them
+# was admitted at the cut: counted on their own and capped like the boundary frames.  Within one spectrum
+# bit-equal norms are ordered as the reference's BinaryHeap pops them (tests/test_gpu_parity.py::
+# test_fft_tie_order_*); what remains here are norms that tie in one implementation's f32 spectrum and
+# differ by an ulp in the other's.
+TIE_FRAC = 0.002
+INV_G_CLAMP = 1.0e3   # fft_err_noise: a sample within 1e-3 of zero does not widen the tolerance any further
 
 
 def _near_threshold(err, max_error):
@@ -106,7 +113,7 @@ def fft_err_noise(fx):
     if not g.size:
         return 0.0
     nu = (4 + np.log2(max(len(fx), 2))) * float(g.max()) * 2.0 ** -23 + 1.00001e-5
-    return nu * float(np.mean(1.0 / g)) * g.size / len(fx)
+    return nu * float(np.mean(np.minimum(1.0 / g, INV_G_CLAMP))) * g.size / len(fx)
 
 
 def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, want_diag=True):
@@ -121,7 +128,7 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
     nf = len(off) - 1
     assert len(frames) == nf
     assert int(rec_off[-1]) == len(rec)
-    summary = {"exact": 0, "tol": 0, "boundary": 0, "fail": [], "codecs": {}, "bytes": len(rec),
+    summary = {"exact": 0, "tol": 0, "tie": 0, "boundary": 0, "fail": [], "codecs": {}, "bytes": len(rec),
                "oracle_bytes": 0, "records": rec, "chosen": chosen, "err": err}
     for i, (fs, sc, tag, payload) in enumerate(frames):
         fx = x[int(off[i]):int(off[i + 1])]
@@ -143,7 +150,7 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
         if verdict.startswith("FAIL"):
             summary["fail"].append((i, verdict))
         elif verdict == "tie":
-            summary["tol"] += 1
+            summary["tie"] += 1
         else:
             summary[verdict] += 1
             if verdict != "boundary":
@@ -166,9 +173,10 @@ def H_varint(v):
 
 
 def assert_summary(summary, nf, what=""):
-    msg = "%s: %d frames exact=%d tol=%d boundary=%d fail=%d %s" % (
-        what, nf, summary["exact"], summary["tol"], summary["boundary"], len(summary["fail"]),
-        summary["fail"][:8])
+    msg = "%s: %d frames exact=%d tol=%d tie=%d boundary=%d fail=%d %s" % (
+        what, nf, summary["exact"], summary["tol"], summary.get("tie", 0), summary["boundary"],
+        len(summary["fail"]), summary["fail"][:8])
     assert not summary["fail"], msg
     assert summary["boundary"] <= max(1, int(BOUNDARY_FRAC * nf)), msg
+    assert summary.get("tie", 0) <= max(1, int(TIE_FRAC * nf)), msg
     return msg

@@ -77,6 +77,65 @@ def _pipe_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _overflow_worker(rank, world, port, q):
+    """A later step produces more bytes than the agreed capacity: nothing may be truncated silently."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from atsc_amd import parallel as P
+
+    dev = torch.device("cpu")
+    small = _fake_records(range(rank * 10, rank * 10 + 30))
+    pg = P.PipelinedGather(dist, torch, rank, world, dev, len(small))
+    # step 1 fits; in step 2 rank 1 alone outgrows the capacity
+    big = _fake_records(range(5000)) if rank == 1 else small
+    assert len(_fake_records(range(5000))) > pg.room
+    bufs = []
+    for i, rec in enumerate((small, big)):
+        b = torch.zeros(max(len(rec), pg.cap) + 64, dtype=torch.uint8)
+        b[: len(rec)] = torch.frombuffer(bytearray(rec), dtype=torch.uint8)
+        bufs.append(b)
+        pg.before_produce(i % 2)
+        pg.submit(i % 2, b, torch.tensor([len(rec)], dtype=torch.int64))
+    pg.drain()
+    over = pg.overflowed()
+    assert over, "the overflow went unnoticed on rank %d" % rank
+    assert not pg.overflowed()  # the flag is consumed
+    assert bytes(bufs[1][: len(big)].numpy().tobytes()) == big  # the record buffer itself was never written to
+    if rank == 0:
+        ok = False
+        try:
+            pg.result(1)
+        except RuntimeError:
+            ok = True
+        assert ok
+        segs, sizes = pg.result(0)  # the step that did fit is intact
+        q.put(("fit", b"".join(bytes(s.numpy().tobytes()) for s in segs)))
+    # the caller's fallback for the step that did not fit: the gather without a capacity
+    out, sizes = P.gather_records(dist, torch, bufs[1], len(big), rank, world)
+    if rank == 0:
+        q.put(("fallback", bytes(out.numpy().tobytes())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_overflow_is_detected():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got["fit"] == b"".join(_fake_records(range(r * 10, r * 10 + 30)) for r in range(world))
+    assert got["fallback"] == _fake_records(range(0, 30)) + _fake_records(range(5000))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pipelined_gather_gloo(world):
     ctx = mp.get_context("spawn")
@@ -113,9 +172,20 @@ def test_shard_range_partitions():
     sys.path.insert(0, ROOT)
     from atsc_amd import parallel as P
 
+    import ctypes as C
+
+    import __graft_entry__ as G
+
+    G.build()
+    from atsc_amd import capi
+
     for n in (1, 7, 8, 4096, 40960):
         for world in (1, 2, 3, 4, 8):
             parts = [P.shard_range(n, r, world) for r in range(world)]
+            for r in range(world):  # the C ABI's split (what a Rust / C host uses) is the same function
+                b, e = C.c_uint64(), C.c_uint64()
+                capi.lib().atsc_shard_range(n, r, world, C.byref(b), C.byref(e))
+                assert (b.value, e.value) == parts[r]
             assert parts[0][0] == 0 and parts[-1][1] == n
             for a, b in zip(parts, parts[1:]):
                 assert a[1] == b[0]

@@ -270,9 +270,51 @@ def _full_size_roundtrip(ctx, A, n_samples, me, seed):
                                                                  for c in np.unique(chosen)}}
 
 
-def test_full_size_config1_1m(ctx, A):
-    r = _full_size_roundtrip(ctx, A, 1 << 20, ME5, seed=0)
-    _log("config 1M roundtrip %r" % r)
+@pytest.mark.parametrize("klass", [1, 0])
+def test_full_size_config1_1m(ctx, A, oracle, klass):
+    """BASELINE.json configs[1] at full size: 2^20 samples in 4096 frames of 256, `--compressor fft`, e = 5 %,
+    once all-C1 (deep ladder) and once all-C0.  Every frame goes through the
+    oracle comparison (trips, K, bin order, coefficients, reported error); then the device-resident round
+    trip: a forced codec is accepted whatever error it reached, so the decoded error is checked against
+    the one the encoder reported."""
+    import torch
+
+    n = 1 << 20
+    x = H.synth_series(0, n, klass=klass)
+    off = H.frame_offsets(n, 256)
+    nf = len(off) - 1
+    s = P.compare_batch(oracle, ctx, x, off, A.FFT, True, ME5)
+    _log(P.assert_summary(s, nf, "configs[1] 1M forced fft class %d" % klass))
+    assert s["codecs"] == {A.FFT: nf}
+    dev = torch.device("cuda:0")
+    plan = ctx.plan(off)
+    d_x = torch.from_numpy(x).to(dev)
+    outs = plan.alloc_outputs(torch, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.compress(d_x, outs, A.FFT, True, ME5, 0, st)
+    torch.cuda.synchronize()
+    total = int(outs["rec_off"][-1].item())
+    body = outs["body"][:total].cpu().numpy().tobytes()
+    assert body == s["records"]  # the device-resident call and the host-pointer call agree
+    err = outs["err"].cpu().numpy()
+    plan.compress(d_x, outs, A.FFT, True, ME5, 0, st)
+    torch.cuda.synchronize()
+    assert outs["body"][:total].cpu().numpy().tobytes() == body  # deterministic
+    dp = A.DPlan(ctx, body)
+    d_body = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(dev)
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    dp.decompress(d_body, d_out, st)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().reshape(nf, 256)
+    xo = x.reshape(nf, 256)
+    fm = np.sum(np.abs((out - xo) / xo), axis=1) / 256.0
+    # the reported error is the mean over the L = 288 Gibbs-padded samples (fft.rs:345): over the 256 real
+    # samples the sum can only be smaller, the divisor is 256 instead of 288
+    assert np.all(fm <= err * 288.0 / 256.0 + 2e-6)
+    ks = [len(H.parse_fft_payload(f[3])[0]) for f in H.parse_bro_body(body, with_count=False)]
+    assert max(ks) <= 25 and min(ks) >= 3  # mf = 3 ... 3 + 17 + 5 (fft.rs:298-302,348-352)
+    _log("configs[1] class %d: ratio %.2f, K %d..%d, worst decoded MAPE %.4f" % (klass, 8.0 * n / (total + 12),
+                                                                                min(ks), max(ks), float(fm.max())))
 
 
 def test_full_size_config2_10m(ctx, A):
@@ -296,11 +338,22 @@ def test_many_small_frames_two_level_pack(ctx, A, oracle):
     assert len(rec) == len(ref)
     fr_g = H.parse_bro_body(rec, with_count=False)
     fr_o = H.parse_bro_body(ref, with_count=False)
-    bad = [i for i in range(nf) if fr_g[i] != fr_o[i] and fr_g[i][2] != oracle.FFT]
+    verdicts = {}
+    bad = []
+    for i in range(nf):
+        if fr_g[i] == fr_o[i]:
+            v = "exact"
+        else:  # every frame that is not byte-identical goes through the frame comparison (FFT tolerances)
+            v = P.compare_frame(oracle, x[i * fl:(i + 1) * fl], ME5, fr_g[i][2], fr_g[i][3], fr_o[i][2], fr_o[i][3],
+                                None, i, None)
+        if v.startswith("FAIL"):
+            bad.append((i, v))
+        verdicts[v if not v.startswith("FAIL") else "fail"] = verdicts.get(v if not v.startswith("FAIL") else "fail", 0) + 1
     assert not bad, bad[:5]
     nfft = sum(1 for f in fr_g if f[2] == oracle.FFT)
-    exact = sum(1 for i in range(nf) if fr_g[i] == fr_o[i])
-    _log("small frames: %d frames, %d fft, %d byte-identical" % (nf, nfft, exact))
+    _log("small frames: %d frames, %d fft, verdicts %r" % (nf, nfft, verdicts))
+    assert verdicts.get("tie", 0) <= max(1, int(P.TIE_FRAC * nf)), verdicts
+    assert verdicts.get("boundary", 0) <= max(1, int(P.BOUNDARY_FRAC * nf)), verdicts
     assert np.all(np.diff(rec_off.astype(np.int64)) > 0)
 
 

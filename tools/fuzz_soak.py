@@ -14,7 +14,7 @@ orc.build()
 ctx = A.Context(0)
 seeds = range(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 130)
 bad = 0
-tot = {"exact": 0, "tol": 0, "boundary": 0, "frames": 0}
+tot = {"exact": 0, "tol": 0, "tie": 0, "boundary": 0, "frames": 0}
 for seed in seeds:
     rng = np.random.default_rng(seed)
     e = int(rng.choice([0, 1, 2, 3, 5, 10, 20, 50]))
@@ -31,7 +31,7 @@ for seed in seeds:
     off = np.array(offs, dtype=np.uint64)
     comp, bounded = [(A.AUTO, True), (A.AUTO, True), (A.FFT, True), (A.POLYNOMIAL, True), (A.RLE, False)][seed % 5]
     s = P.compare_batch(orc, ctx, x, off, comp, bounded, me)
-    for k in ("exact", "tol", "boundary"):
+    for k in ("exact", "tol", "tie", "boundary"):
         tot[k] += s[k]
     tot["frames"] += len(offs) - 1
     line = "seed %d e=%d comp=%d uniform=%d exact=%d tol=%d boundary=%d fail=%d" % (
