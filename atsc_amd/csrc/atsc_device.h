@@ -454,6 +454,82 @@ DEVI double recip_abs(double g)
     return 1.0 / a;
 }
 
+// --------------------------------------------------------------------------------------------
+// Order of admission among bins of EQUAL norm.  FFT::fft_trim (fft.rs:231-257) pops its top-K from a
+// std::collections::BinaryHeap built over all bins in position order; FrequencyPoint's Ord looks at the
+// f32 norm only (fft.rs:88-106), so bins whose norms are bit-equal leave the heap in an order that
+// depends on the heap's internals (Rust 1.81: rebuild = sift_down_range from len/2 - 1 down to 0;
+// pop = swap_remove(0) + sift_down_to_bottom(0) + sift_up), and the order is serialised.  The sorted
+// / lazy selection of the kernels is that pop sequence whenever the admitted norms are distinct; when
+// they are not, the frame replays the heap itself: entries (norm bits << 32 | position) in LDS, every
+// lane of one wavefront running the same sequential code (oracle/atsc_oracle.c heap_* is the same
+// algorithm on the CPU).  Compares are the reference's: a <= b is !(na > nb), a >= b is na >= nb.
+// --------------------------------------------------------------------------------------------
+DEVI float hp_norm(uint64_t e) { return __uint_as_float((uint32_t)(e >> 32)); }
+DEVI void hp_sift_down_range(uint64_t *h, uint32_t pos, uint32_t end)
+{
+    const uint64_t elt = h[pos];
+    const float en = hp_norm(elt);
+    uint32_t child = 2 * pos + 1;
+    while (end >= 2 && child <= end - 2) {
+        const uint64_t c0 = h[child], c1 = h[child + 1];
+        const bool right = !(hp_norm(c0) > hp_norm(c1));  // hole.get(child) <= hole.get(child + 1)
+        const uint64_t c = right ? c1 : c0;
+        child += right ? 1u : 0u;
+        if (en >= hp_norm(c)) { h[pos] = elt; return; }
+        h[pos] = c;
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (end >= 1 && child == end - 1) {
+        const uint64_t c = h[child];
+        if (!(en >= hp_norm(c))) { h[pos] = c; pos = child; }  // hole.element() < hole.get(child)
+    }
+    h[pos] = elt;
+}
+DEVI void hp_rebuild(uint64_t *h, uint32_t len)
+{
+    for (uint32_t n = len / 2; n > 0;) {
+        --n;
+        hp_sift_down_range(h, n, len);
+    }
+}
+// BinaryHeap::pop; the popped entry is also left at h[len - 1] (the slot the heap gives up), so K pops of
+// a heap of `len` entries leave the pop sequence at h[len - 1], h[len - 2], ...
+DEVI uint64_t hp_pop(uint64_t *h, uint32_t &len)
+{
+    uint64_t item = h[--len];
+    if (len > 0) {
+        const uint64_t top = h[0];
+        const float en = hp_norm(item);
+        // sift_down_to_bottom(0)
+        uint32_t pos = 0, child = 1;
+        while (len >= 2 && child <= len - 2) {
+            const uint64_t c0 = h[child], c1 = h[child + 1];
+            const bool right = !(hp_norm(c0) > hp_norm(c1));
+            h[pos] = right ? c1 : c0;
+            pos = child + (right ? 1u : 0u);
+            child = 2 * pos + 1;
+        }
+        if (child == len - 1) {
+            h[pos] = h[child];
+            pos = child;
+        }
+        // sift_up(0, pos)
+        while (pos > 0) {
+            const uint32_t parent = (pos - 1) >> 1;
+            const uint64_t pe = h[parent];
+            if (!(en > hp_norm(pe))) break;  // hole.element() <= hole.get(parent)
+            h[pos] = pe;
+            pos = parent;
+        }
+        h[pos] = item;
+        item = top;
+    }
+    h[len] = item;
+    return item;
+}
+
 struct Sel {
     uint32_t pos;
     float re, im;

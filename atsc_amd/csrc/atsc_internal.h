@@ -220,3 +220,6 @@ static inline bool host_next_record(const uint8_t *b, uint64_t len, uint64_t &po
 // test hook (tests/asan): the host half of atsc_dplan_create on untrusted bytes, no GPU needed
 extern "C" int atsc_internal_dplan_parse(const uint8_t *body, uint64_t body_len, int has_count,
                                          uint64_t *n_frames, uint64_t *n_samples);
+// test hook: the order in which the kernels' heap replay (hp_*, atsc_device.h) pops `k` of `bins` entries
+// with the given f32 norms (runs a one-wavefront kernel; needs a GPU)
+extern "C" int atsc_internal_heap_order(const float *norms, uint32_t bins, uint32_t k, uint32_t *order);

@@ -901,6 +901,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             uint32_t nb[KPL];
             float bre[KPL], bim[KPL];  // W == 1: the lane's bins, so an admitted bin is one v_readlane away
             uint64_t *keys = (uint64_t *)(spec == A ? B : A);
+            bool heap_order = false;  // bit-equal norms met: the admission order is replayed from the reference's heap
+            uint32_t hlen = 0;        // W == 1: entries left in the heap (keys[])
             uint32_t nz = 0;
             if (W == 1) {
 #pragma unroll
@@ -985,6 +987,50 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 uint32_t p2 = 1;
                 while (p2 < nk) p2 <<= 1;
                 block_sort<W, true>(keys, nullptr, nk, p2);
+                // Bit-equal norms among the bins the ladder can admit (or at the cut behind them): the
+                // reference's order is the BinaryHeap's, not (norm, position) -- replay the heap (hp_*,
+                // atsc_device.h).  Rare: two of <= kcap f32 norms have to collide.
+                uint32_t tied = 0;  // (matches of the cut norm) << 16 | adjacent equal pairs seen by this thread
+                for (uint32_t i = tid; i + 1 < nk; i += T) {  // (zero norms, key half 0xFFFFFFFF, are never admitted)
+                    const uint32_t hi = (uint32_t)(keys[i] >> 32);
+                    tied += (hi == (uint32_t)(keys[i + 1] >> 32) && hi != 0xFFFFFFFFu) ? 1u : 0u;
+                }
+                if (nk < bins && nk > 0 && (uint32_t)(keys[nk - 1] >> 32) != 0xFFFFFFFFu) {  // a bin left out by the select may tie with the last one kept
+                    const uint32_t last = (uint32_t)(keys[nk - 1] >> 32);
+                    for (uint32_t k = tid; k < bins; k += T) {
+                        const float2 z = spec[k];
+                        const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                        // (the kept copy of the last key itself is one match; a second one is a tie)
+                        tied += ((~__float_as_uint(nrm)) == last) ? 0x10000u : 0u;
+                    }
+                }
+                tied = block_sum_u32<W>(tied, red, parity);
+                // every bin whose norm equals the cut norm sorts in front of the cut or right behind it: more
+                // matches over all bins than inside the kept list means the tie group straddles the cut
+                if ((tied & 0xffffu) != 0) heap_order = true;
+                if (nk < bins && nk > 0 && (uint32_t)(keys[nk - 1] >> 32) != 0xFFFFFFFFu) {
+                    uint32_t inside = 0;
+                    const uint32_t last = (uint32_t)(keys[nk - 1] >> 32);
+                    for (uint32_t i = tid; i < nk; i += T) inside += ((uint32_t)(keys[i] >> 32) == last) ? 1u : 0u;
+                    inside = block_sum_u32<W>(inside, red, parity);
+                    if ((tied >> 16) > inside) heap_order = true;
+                }
+                if (heap_order) {
+                    __syncthreads();
+                    for (uint32_t k = tid; k < bins; k += T) {
+                        const float2 z = spec[k];
+                        const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                        keys[k] = ((uint64_t)__float_as_uint(nrm) << 32) | (uint64_t)k;
+                    }
+                    __syncthreads();
+                    if (tid < 64) {
+                        hp_rebuild(keys, bins);
+                        uint32_t hl = bins;
+                        const uint32_t want = min(kcap, Z);
+                        for (uint32_t i = 0; i < want; ++i) (void)hp_pop(keys, hl);  // pop i lands at keys[bins - 1 - i]
+                    }
+                    __syncthreads();
+                }
             }
 
             if (prm.debug_stop == 5) return;
@@ -1012,15 +1058,41 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     uint32_t pos;
                     float2 z;
                     if (W == 1) {
-                        uint32_t lm = nb[0];
+                        pos = 0;
+                        if (!heap_order) {
+                            uint32_t lm = nb[0];
 #pragma unroll
-                        for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
-                        const uint32_t wm = wave_max_u32(lm);
-                        uint32_t cand = 0xFFFFFFFFu;
+                            for (int m = 1; m < KPL; ++m) lm = max(lm, nb[m]);
+                            const uint32_t wm = wave_max_u32(lm);
+                            // lowest position holding the largest norm, and how many bins hold it
+                            uint32_t mult = 0;
 #pragma unroll
-                        for (int m = KPL - 1; m >= 0; --m)
-                            if (nb[m] == wm) cand = tid + 64 * m;
-                        pos = wave_min_u32(cand);
+                            for (int m = KPL - 1; m >= 0; --m) {
+                                const uint64_t bal = __ballot(nb[m] == wm);
+                                mult += (uint32_t)__popcll(bal);
+                                if (bal) pos = 64u * (uint32_t)m + (uint32_t)__builtin_ctzll(bal);
+                            }
+                            if (mult > 1) {
+                                // Bit-equal norms: from here on the bins come out of the reference's heap.  The
+                                // bins admitted so far had distinct norms, i.e. they are the heap's first pops.
+                                __syncthreads();
+#pragma unroll
+                                for (int m = 0; m < KPL; ++m) {
+                                    const uint32_t k = tid + 64 * m;
+                                    if (k < bins) {
+                                        const float nrm = (float)sqrt((double)bre[m] * (double)bre[m] +
+                                                                      (double)bim[m] * (double)bim[m]);
+                                        keys[k] = ((uint64_t)__float_as_uint(nrm) << 32) | (uint64_t)k;
+                                    }
+                                }
+                                __syncthreads();
+                                hp_rebuild(keys, bins);
+                                hlen = bins;
+                                for (uint32_t i = 0; i < used; ++i) (void)hp_pop(keys, hlen);
+                                heap_order = true;
+                            }
+                        }
+                        if (heap_order) pos = (uint32_t)(hp_pop(keys, hlen) & 0xffffffffu);
                         float zr = 0.0f, zi = 0.0f;
 #pragma unroll
                         for (int m = 0; m < KPL; ++m) {
@@ -1030,7 +1102,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         z = make_float2(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zr), pos & 63)),
                                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zi), pos & 63)));
                     } else {
-                        pos = (uint32_t)(keys[used] & 0xffffffffu);
+                        pos = (uint32_t)(keys[heap_order ? bins - 1 - used : used] & 0xffffffffu);
                         z = spec[pos];
                     }
                     if (tid == 0) { sel[used].pos = pos; sel[used].re = z.x; sel[used].im = z.y; }
@@ -1522,6 +1594,49 @@ __global__ __launch_bounds__(256) void k_pack_emit_big(const DevFrame *__restric
     }
     if (whole + threadIdx.x < r.len) pd[whole + threadIdx.x] = src[whole + threadIdx.x];
 }
+
+// --------------------------------------------------------------------------------------------
+// Test hook (declared in atsc_internal.h, not part of the public ABI): the pop order of the heap replay
+// (hp_*) for a given array of norms, so that tests can hold it against the oracle's restatement of
+// std::collections::BinaryHeap on arbitrary tie patterns.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_test_heap_order(const float *__restrict__ norms, uint32_t bins, uint32_t k,
+                                                        uint32_t *__restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *h = (uint64_t *)smem;
+    for (uint32_t i = threadIdx.x; i < bins; i += 64) h[i] = ((uint64_t)__float_as_uint(norms[i]) << 32) | (uint64_t)i;
+    __syncthreads();
+    hp_rebuild(h, bins);
+    uint32_t len = bins;
+    for (uint32_t i = 0; i < k && len > 0; ++i) {
+        const uint32_t pos = (uint32_t)(hp_pop(h, len) & 0xffffffffu);
+        if (threadIdx.x == 0) order[i] = pos;
+    }
+}
+}  // namespace atsc
+extern "C" int atsc_internal_heap_order(const float *norms, uint32_t bins, uint32_t k, uint32_t *order)
+{
+    if (!norms || !order || bins == 0 || k > bins || bins > 8000) return ATSC_E_INVALID;
+    float *d_n = nullptr;
+    uint32_t *d_o = nullptr;
+    int rc = ATSC_E_HIP;
+    const uint32_t lds = bins * 8;
+    if (hipMalloc((void **)&d_n, bins * sizeof(float)) != hipSuccess) return ATSC_E_HIP;
+    if (hipMalloc((void **)&d_o, (k ? k : 1) * sizeof(uint32_t)) == hipSuccess &&
+        hipMemcpy(d_n, norms, bins * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+        (lds <= 48 * 1024 || hipFuncSetAttribute((const void *)atsc::k_test_heap_order,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)) {
+        hipLaunchKernelGGL(atsc::k_test_heap_order, dim3(1), dim3(64), lds, nullptr, d_n, bins, k, d_o);
+        if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(order, d_o, k * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            rc = ATSC_OK;
+    }
+    (void)hipFree(d_n);
+    (void)hipFree(d_o);
+    return rc;
+}
+namespace atsc {
 
 // --------------------------------------------------------------------------------------------
 // launchers

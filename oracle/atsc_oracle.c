@@ -945,6 +945,26 @@ static int heap_pop(fpoint *d, size_t *len, fpoint *out)
     return 1;
 }
 
+/* Test support: the pop order of BinaryHeap::from(bins in position order) for bins with the given f32
+ * norms (fft.rs:245-255 as fft_trim uses it) -- what the GPU's heap replay is held against.  Each bin is
+ * the point (norm, 0), whose hypotf is the norm itself; n <= 65536 (pos is a u16, fft.rs:36). */
+int orc_heap_order(const float *norms, size_t n, size_t k, uint32_t *out)
+{
+    if (!norms || !out || k > n || n > 65536) return -1;
+    fpoint *d = (fpoint *)malloc((n ? n : 1) * sizeof(fpoint));
+    if (!d) return -2;
+    for (size_t i = 0; i < n; i++) { d[i].pos = (uint16_t)i; d[i].re = norms[i]; d[i].im = 0.0f; }
+    size_t len = n;
+    heap_rebuild(d, len);
+    for (size_t i = 0; i < k; i++) {
+        fpoint it;
+        if (!heap_pop(d, &len, &it)) break;
+        out[i] = it.pos;
+    }
+    free(d);
+    return 0;
+}
+
 /* fft.rs:231-257 */
 static void fft_trim(fft_t *f, const c32 *half, size_t nbins, size_t max_freq)
 {

@@ -117,6 +117,8 @@ int orc_stream_compress(const double *x, const uint64_t *chunk_off, size_t n_chu
 int orc_compress_data(const double *x, size_t n, int compressor, uint8_t cli_error, int level,
                       orc_buf *out);
 /* main.rs:168-172 decompress_data (from_bytes + decompress).  returns <0 on bad magic/version */
+/* test support: pop order of the reference's BinaryHeap over bins with these f32 norms (n <= 65536) */
+int orc_heap_order(const float *norms, size_t n, size_t k, uint32_t *out);
 int orc_decompress_data(const uint8_t *bro, size_t len, double **out, size_t *out_n);
 
 #ifdef __cplusplus

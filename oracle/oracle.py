@@ -280,6 +280,19 @@ def stream_compress(x, chunk_off, compressor, bounded, max_error=0.0, level=0):
     return _take(b), chosen[:nch], errs[:nch]
 
 
+def heap_order(norms, k):
+    """Pop order (bin positions) of the reference's BinaryHeap over bins with these f32 norms."""
+    a = np.ascontiguousarray(np.asarray(norms, dtype=np.float32))
+    out = np.zeros(max(k, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_heap_order.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.orc_heap_order.restype = C.c_int
+    rc = L.orc_heap_order(a.ctypes.data_as(C.POINTER(C.c_float)), len(a), k, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc:
+        raise RuntimeError("orc_heap_order rc=%d" % rc)
+    return out[:k]
+
+
 def compress_data(x, compressor, cli_error=3, level=0):
     a, pa = _arr(x)
     b = _Buf()

@@ -1038,3 +1038,85 @@ def test_large_frames_grid_and_single_kernel_forms_agree(ctx, A, monkeypatch):
         if not differ:
             assert np.allclose(err_g, err_1, rtol=1e-9, atol=1e-15, equal_nan=True)
         assert np.array_equal(out_g, out_1, equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------
+# Bins of equal norm: the admission order is the reference's BinaryHeap pop order (fft.rs:231-257)
+# ---------------------------------------------------------------------------------------
+def _gpu_heap_order(A, norms, k):
+    import ctypes as C
+
+    a = np.ascontiguousarray(np.asarray(norms, dtype=np.float32))
+    out = np.zeros(max(k, 1), dtype=np.uint32)
+    fn = A.capi.lib().atsc_internal_heap_order  # test hook, atsc_internal.h
+    fn.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    fn.restype = C.c_int
+    rc = fn(a.ctypes.data_as(C.POINTER(C.c_float)), len(a), k, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == 0
+    return out[:k]
+
+
+def test_fft_tie_order_heap_replay_matches_binaryheap(ctx, A, oracle):
+    """The kernels' heap replay (hp_*, atsc_device.h) against the oracle's restatement of
+    std::collections::BinaryHeap (Rust 1.81) on norm arrays full of ties: a few distinct values, all
+    equal, two values, sorted, reversed, with zeros -- 7 ... 2188 bins (n = 12 ... 4096), every K."""
+    rng = np.random.default_rng(12)
+    cases = 0
+    for bins in (7, 13, 33, 65, 73, 145, 163, 289, 577, 1094, 2188):
+        pats = [np.ones(bins), np.arange(bins) % 2 + 1.0, np.arange(bins) % 3 + 1.0, (np.arange(bins) // 4) + 1.0,
+                (bins - np.arange(bins)) // 3 + 1.0, rng.integers(1, 4, bins).astype(float),
+                rng.integers(1, max(bins // 8, 2), bins).astype(float), rng.integers(0, 3, bins).astype(float),
+                np.round(rng.random(bins) * 8) / 8 + 0.125, rng.random(bins)]
+        for pat in pats:
+            k = bins if bins <= 600 else 450
+            g = _gpu_heap_order(A, pat, k)
+            o = oracle.heap_order(pat, k)
+            assert np.array_equal(g, o), (bins, pat[:16], g[:16], o[:16])
+            # and it is a descending-norm order, as any heap's
+            assert np.all(np.diff(np.asarray(pat, dtype=np.float32)[g]) <= 0)
+            cases += 1
+    _log("heap replay == BinaryHeap order on %d tie patterns" % cases)
+
+
+@pytest.mark.parametrize("bounded", [True, False])
+def test_fft_tie_order_impulse_frames(ctx, A, oracle, bounded):
+    """Frames whose spectrum ties exactly in both implementations: x = [a, 0, 0, ...] transformed at its own
+    length (every bin is (a, +0): the only non-zero input meets twiddle 1 in any butterfly order), i.e. the
+    bounded path below 128 samples and FFT::compress (no padding) at any 2^a 3^b length.  All bins tie, so the
+    stored order is purely the heap's: the payloads must be byte-identical to the oracle's."""
+    lens = [8, 12, 17, 31, 64, 100, 127] if bounded else [12, 64, 127, 128, 144, 256, 288, 512, 1024, 2048, 2187, 4096]
+    n_exact = 0
+    for n in lens:
+        for a in (5.0, -3.25, 1000.0):
+            x = np.zeros(n)
+            x[0] = a
+            off = np.array([0, n], dtype=np.uint64)
+            rec, _, chosen, _ = ctx.compress_host(x, off, A.FFT, bounded, ME5, 0)
+            po, _ = oracle.compress(oracle.FFT, x, bounded, ME5)
+            (fs, sc, tag, payload), = H.parse_bro_body(rec, with_count=False)
+            fg, _, _ = H.parse_fft_payload(payload)
+            fo, _, _ = H.parse_fft_payload(po)
+            assert [f[0] for f in fg] == [f[0] for f in fo], (n, a, [f[0] for f in fg][:12], [f[0] for f in fo][:12])
+            assert payload == po, (n, a)
+            n_exact += 1
+    _log("impulse frames (all bins tie), bounded=%s: %d payloads byte-identical to the oracle" % (bounded, n_exact))
+
+
+def test_fft_tie_order_mixed_batch(ctx, A, oracle):
+    """Tie frames inside an ordinary batch (the one-wavefront class switches to the heap replay in the
+    middle of its ladder; its neighbours are unaffected): auto and forced FFT, frames of 64 and 100 samples."""
+    for n in (64, 100):
+        xs = []
+        for k in range(40):
+            if k % 4 == 0:
+                v = np.zeros(n)
+                v[0] = 10.0 + k
+            else:
+                v = H.synth_series(700 + k, n, klass=k % 4)
+            xs.append(v)
+        x = np.concatenate(xs)
+        off = H.frame_offsets(len(x), n)
+        for comp in (A.FFT, A.AUTO):
+            s = P.compare_batch(oracle, ctx, x, off, comp, True, ME5)
+            _log(P.assert_summary(s, 40, "tie frames in a mixed batch n=%d comp=%d" % (n, comp)))
+            assert s["tie"] == 0
