@@ -377,8 +377,7 @@ static hipError_t launch_d(uint32_t count, uint32_t lds, const DevDFrame *frames
 {
     auto kern = k_decompress<W, SPL>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dyn_lds((const void *)kern, lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, frames, ids, plans, twpool, body, out,

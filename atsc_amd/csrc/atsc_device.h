@@ -6,9 +6,30 @@
 #include "../../include/atsc_hip.h"
 #include "atsc_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace atsc {
 
 #define DEVI __device__ __forceinline__
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) and size step instead of once per
+// launch: in a process that has many code objects loaded (PyTorch) one such call was measured at ~5 ms, and
+// the large tier made six per batch.
+inline hipError_t ensure_dyn_lds(const void *fn, uint32_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, uint32_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    uint32_t &have = done[std::make_pair(dev, fn)];
+    if (bytes <= have) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 // --------------------------------------------------------------------------------------------
 // Rust `as` casts (saturating, NaN -> 0) and bincode varints

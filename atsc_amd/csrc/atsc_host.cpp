@@ -4,12 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <string>
@@ -41,7 +43,8 @@ hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, cons
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
-                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s);
+                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s, uint64_t *chain = nullptr);
+hipError_t launch_nonfinite_flag(const double *x, uint64_t n, uint32_t *flag, hipStream_t s);
 hipError_t launch_decompress(const struct DevDFrame *frames, uint64_t n_frames, const uint32_t *ids,
                              int cls, uint32_t count, uint32_t lds, const DevPlan *plans,
                              const float2 *twpool, const uint8_t *body, double *out, int *status,
@@ -78,6 +81,18 @@ struct atsc_ctx {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    // Host-pointer entry points (atsc_compress_frames ...): plans kept by frame layout (a service compresses
+    // the same layout batch after batch; building a plan walks every frame and uploads its tables), and a
+    // stream of their own so that the blocking host-to-device copy of one part of a batch does not order
+    // itself behind the kernels of the part before it (the legacy default stream would).
+    struct CachedPlan {
+        uint64_t hash = 0, stamp = 0;
+        std::vector<uint32_t> lens;
+        atsc_plan *plan = nullptr;
+    };
+    std::vector<CachedPlan> plan_cache;
+    uint64_t plan_stamp = 0;
+    hipStream_t work_stream = nullptr;
 };
 
 struct PlanTables {
@@ -299,6 +314,36 @@ static int class_of(uint32_t n, uint32_t L)
     return -1;
 }
 
+// (cos, sin)(2 pi t / L), t < L, rounded from f64.  A 131072-sample frame's table is 139968 libm calls
+// twice over -- milliseconds, per plan and per decode plan -- so the tables are kept for the life of the
+// process (up to TW_CACHE_MAX entries in all; beyond that they are recomputed).
+static void twiddle_table(uint32_t L, float2 *out)
+{
+    static std::mutex mu;
+    static std::map<uint32_t, std::vector<float2>> cache;
+    static size_t held = 0;
+    const size_t TW_CACHE_MAX = 16u << 20;  // 16 M entries = 128 MB
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(L);
+        if (it != cache.end()) {
+            memcpy(out, it->second.data(), (size_t)L * sizeof(float2));
+            return;
+        }
+    }
+    for (uint32_t t = 0; t < L; ++t) {
+        const double a = 2.0 * 3.14159265358979323846 * (double)t / (double)L;
+        out[t] = make_float2((float)cos(a), (float)sin(a));
+    }
+    if (L >= 512) {
+        std::lock_guard<std::mutex> g(mu);
+        if (held + L <= TW_CACHE_MAX && !cache.count(L)) {
+            cache[L].assign(out, out + L);
+            held += L;
+        }
+    }
+}
+
 // Fills the per-length table entry (see DevPlan) and appends the twiddle table of L if new.
 static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64_t> &tw_by_L,
                             bool nopad = false, bool dec = false)
@@ -401,10 +446,7 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         tw_by_L[p.L] = off;
         p.tw_off = off;
         T.twpool.resize(off + p.L);
-        for (uint32_t t = 0; t < p.L; ++t) {
-            const double a = 2.0 * 3.14159265358979323846 * (double)t / (double)p.L;
-            T.twpool[off + t] = make_float2((float)cos(a), (float)sin(a));
-        }
+        twiddle_table(p.L, T.twpool.data() + off);
     } else {
         p.tw_off = it->second;
     }
@@ -477,6 +519,9 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
 extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
 {
     if (!ctx) return;
+    for (auto &cp : ctx->plan_cache) atsc_plan_destroy(cp.plan);
+    ctx->plan_cache.clear();
+    if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
@@ -804,7 +849,7 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
 static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
                          int compressor, int bounded, float max_error, int sample_level,
                          uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
-                         uint8_t *d_chosen, double *d_err, void *stream, bool pipelined)
+                         uint8_t *d_chosen, double *d_err, void *stream, bool pipelined, uint64_t *d_chain = nullptr)
 {
     if (!ctx || !plan || !d_samples || !d_body || !d_rec_off) return fail(ctx, ATSC_E_INVALID, "compress: null argument");
     if (sample_level < 0 || sample_level > 6) return fail(ctx, ATSC_E_INVALID, "compress: sample level");
@@ -879,7 +924,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         }
         hipError_t e = launch_pack(plan->d_frames, S.d_res, plan->n_frames, S.d_local, S.d_blocksum,
                                    S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err,
-                                   plan->d_ids + plan->class_first[CLASS_LARGE], plan->class_count[CLASS_LARGE], ps);
+                                   plan->d_ids + plan->class_first[CLASS_LARGE], plan->class_count[CLASS_LARGE], ps, d_chain);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
         if (pipelined) {
             if (adapt && want_order) {
@@ -1060,28 +1105,115 @@ extern "C" int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream
     return ATSC_OK;
 }
 
-extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
-                                    uint64_t n_frames, int compressor, int bounded, float max_error,
-                                    int sample_level, uint8_t *body, uint64_t body_cap,
-                                    uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen,
-                                    double *err)
+// Plan for frames [f0, f1) of a caller's offset array, from the context's cache when the layout was seen before.
+static const size_t PLAN_CACHE_MAX = 4;
+static int cached_plan(atsc_ctx *ctx, const uint64_t *frame_off, uint64_t f0, uint64_t f1, atsc_plan **out)
 {
-    ATSC_API_BEGIN
-    if (!ctx || !samples || !frame_off || !body || !body_len) return fail(ctx, ATSC_E_INVALID, "compress_frames: null argument");
-    if (n_frames == 0) return fail(ctx, ATSC_E_INVALID, "compress_frames: no frames");
-    // re-base offsets so that frame_off[0] maps to d_x[0]
-    std::vector<uint64_t> rel(n_frames + 1);
-    for (uint64_t i = 0; i <= n_frames; ++i) rel[i] = frame_off[i] - frame_off[0];
+    const uint64_t nf = f1 - f0;
+    uint64_t h = 0xcbf29ce484222325ull ^ nf;
+    for (uint64_t f = f0; f < f1; ++f) {
+        const uint64_t len = frame_off[f + 1] - frame_off[f];
+        if (frame_off[f + 1] <= frame_off[f]) return fail(ctx, ATSC_E_INVALID, "compress_frames: empty or unordered frame");
+        if (len > MAX_FRAME) return fail(ctx, ATSC_E_UNSUPPORTED, "compress_frames: frame longer than 131072 samples");
+        h = (h ^ len) * 0x100000001b3ull;
+    }
+    for (auto &cp : ctx->plan_cache) {
+        if (cp.hash != h || cp.lens.size() != nf) continue;
+        bool same = true;
+        for (uint64_t f = 0; f < nf && same; ++f) same = cp.lens[f] == (uint32_t)(frame_off[f0 + f + 1] - frame_off[f0 + f]);
+        if (!same) continue;
+        cp.stamp = ++ctx->plan_stamp;
+        *out = cp.plan;
+        return ATSC_OK;
+    }
+    std::vector<uint64_t> rel(nf + 1);
+    for (uint64_t i = 0; i <= nf; ++i) rel[i] = frame_off[f0 + i] - frame_off[f0];
     atsc_plan *plan = nullptr;
-    int rc = atsc_plan_create(ctx, rel.data(), n_frames, &plan);
+    int rc = atsc_plan_create(ctx, rel.data(), nf, &plan);
     if (rc) return rc;
-    const uint64_t ns = rel[n_frames];
-    const uint64_t bound = atsc_plan_body_bound(plan);
+    if (ctx->plan_cache.size() >= PLAN_CACHE_MAX) {  // drop the layout used longest ago
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx->plan_cache.size(); ++i)
+            if (ctx->plan_cache[i].stamp < ctx->plan_cache[victim].stamp) victim = i;
+        atsc_plan_destroy(ctx->plan_cache[victim].plan);
+        ctx->plan_cache.erase(ctx->plan_cache.begin() + (long)victim);
+    }
+    atsc_ctx::CachedPlan cp;
+    cp.hash = h;
+    cp.stamp = ++ctx->plan_stamp;
+    cp.lens.resize(nf);
+    for (uint64_t f = 0; f < nf; ++f) cp.lens[f] = (uint32_t)(rel[f + 1] - rel[f]);
+    cp.plan = plan;
+    ctx->plan_cache.push_back(std::move(cp));
+    *out = plan;
+    return ATSC_OK;
+}
+
+// Host-pointer compress.  The time goes into the host-to-device copy of the samples (PCIe: 84 MB take
+// 1.5 ms, the kernels 0.2 ms), so a batch of equal-length small frames is cut into parts: while the blocking
+// copy of part i + 1 runs, the kernels of part i do (on the context's own stream); what is left behind the
+// last copy is one part's kernels and the copy of the records.  The parts share one cached plan (same
+// layout), run in stream order, and their records are laid end to end: the bytes are those of one call.
+// nonfinite (optional): receives 1 when a sample is NaN or infinite (checked on the device, atsc_compress_data)
+// out_alloc (optional, then `body` is ignored): the records go to a malloc'd block of head_room + *body_len bytes,
+// behind head_room bytes left for the caller -- sized once the length is known.  (Handing in a worst-case buffer
+// of hundreds of megabytes and shrinking it afterwards is expensive beyond the allocation: the runtime pins
+// the pages a device-to-host copy lands in, and unmapping the rest of such a block stalled the NEXT
+// host-to-device copy by 28 ms in a process that also runs PyTorch.)
+static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                                uint64_t n_frames, int compressor, int bounded, float max_error,
+                                int sample_level, uint8_t *body, uint64_t body_cap,
+                                uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen,
+                                double *err, int *nonfinite, uint64_t head_room = 0, uint8_t **out_alloc = nullptr)
+{
+    if (!ctx || !samples || !frame_off || (!body && !out_alloc) || !body_len) return fail(ctx, ATSC_E_INVALID, "compress_frames: null argument");
+    if (out_alloc) *out_alloc = nullptr;
+    if (n_frames == 0) return fail(ctx, ATSC_E_INVALID, "compress_frames: no frames");
+    static const bool trace = getenv("ATSC_TRACE_HOST") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[compress] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->work_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->work_stream, hipStreamNonBlocking));
+    const uint64_t ns = frame_off[n_frames] - frame_off[0];
+    // parts: only for uniform frames of the LDS-resident tiers (the large tier runs best with every frame in one launch)
+    const uint64_t fl = frame_off[1] - frame_off[0];
+    bool uniform = fl >= 1 && fl <= MAX_FRAME;
+    for (uint64_t f = 1; f < n_frames && uniform; ++f) uniform = (frame_off[f + 1] - frame_off[f]) == fl;
+    uint64_t parts = 1;
+    if (uniform) {
+        // (large frames run best many to a launch: two parts, and only when each still has 32 frames)
+        parts = fl <= MAX_FRAME_TIER_M ? std::min<uint64_t>(8, std::max<uint64_t>(1, ns >> 21)) : (n_frames >= 64 ? 2 : 1);
+        if (const char *e = getenv("ATSC_HOST_PARTS")) parts = std::max(1, atoi(e));
+        if (ctx->want_diag) parts = 1;  // atsc_ctx_last_diag reports one launch
+        parts = std::min(parts, n_frames);
+    }
+    const uint64_t per = (n_frames + parts - 1) / parts;
+    parts = (n_frames + per - 1) / per;
+    struct Part { uint64_t f0, f1; atsc_plan *plan; };
+    std::vector<Part> pt(parts);
+    uint64_t bound = 0;
+    for (uint64_t g = 0; g < parts; ++g) {
+        pt[g].f0 = g * per;
+        pt[g].f1 = std::min(n_frames, (g + 1) * per);
+        int rc = cached_plan(ctx, frame_off, pt[g].f0, pt[g].f1, &pt[g].plan);
+        if (rc) return rc;
+        bound += atsc_plan_body_bound(pt[g].plan);
+    }
+    lap("plans");
+    int rc = ATSC_OK;
     double *d_x = nullptr, *d_err = nullptr;
     uint8_t *d_body = nullptr, *d_ch = nullptr;
-    uint64_t *d_off = nullptr;
-    std::vector<uint64_t> h_off(n_frames + 1);
+    uint64_t *d_off = nullptr;  // part g's n_g + 1 offsets start at f0_g + g; then parts + 1 chain words:
+                                // chain[g] = where part g's records start in d_body (k_pack_emit)
+    std::vector<uint64_t> h_off;
+    uint64_t total = 0;
     hipError_t e = hipSuccess;
+    hipStream_t ws = ctx->work_stream;
 #define FCHK(call)                                            \
     do {                                                      \
         e = (call);                                           \
@@ -1089,30 +1221,91 @@ extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const 
     } while (0)
     FCHK(pool_alloc(ctx, (void **)&d_x, ns * sizeof(double)));
     FCHK(pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(bound, 16)));
-    FCHK(pool_alloc(ctx, (void **)&d_off, (n_frames + 1) * sizeof(uint64_t)));
+    FCHK(pool_alloc(ctx, (void **)&d_off, (n_frames + 2 * parts + 2) * sizeof(uint64_t)));  // ... then the non-finite flag
     FCHK(pool_alloc(ctx, (void **)&d_ch, n_frames));
     FCHK(pool_alloc(ctx, (void **)&d_err, n_frames * sizeof(double)));
-    FCHK(hipMemcpy(d_x, samples + frame_off[0], ns * sizeof(double), hipMemcpyHostToDevice));
-    rc = atsc_compress_plan_dev(ctx, plan, d_x, compressor, bounded, max_error, sample_level, d_body,
-                                bound, d_off, d_ch, d_err, nullptr);
-    if (rc) goto done;
-    FCHK(hipStreamSynchronize(nullptr));
-    FCHK(hipMemcpy(h_off.data(), d_off, (n_frames + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    *body_len = h_off[n_frames];
-    if (h_off[n_frames] > body_cap) { rc = fail(ctx, ATSC_E_CAPACITY, "compress_frames: body_cap"); goto done; }
-    FCHK(hipMemcpy(body, d_body, h_off[n_frames], hipMemcpyDeviceToHost));
-    if (rec_off) memcpy(rec_off, h_off.data(), (n_frames + 1) * sizeof(uint64_t));
+    lap("alloc");
+    FCHK(hipMemsetAsync(d_off + n_frames + parts, 0, sizeof(uint64_t), ws));
+    FCHK(hipMemsetAsync(d_off + n_frames + 2 * parts + 1, 0, sizeof(uint64_t), ws));
+    for (uint64_t g = 0; g < parts; ++g) {
+        const uint64_t s0 = frame_off[pt[g].f0] - frame_off[0], s1 = frame_off[pt[g].f1] - frame_off[0];
+        // (pieces of at most 16 MB: one pageable copy of 40 MB and more has been seen to take 10-15 ms -- the
+        // runtime pins such a source on the fly -- where the same bytes in smaller calls go at the link's rate)
+        for (uint64_t c0 = s0; c0 < s1; c0 += (2u << 20)) {
+            const uint64_t c1 = std::min<uint64_t>(s1, c0 + (2u << 20));
+            FCHK(hipMemcpy(d_x + c0, samples + frame_off[0] + c0, (c1 - c0) * sizeof(double), hipMemcpyHostToDevice));
+        }
+        lap("  part copy");
+        if (nonfinite) FCHK(launch_nonfinite_flag(d_x + s0, s1 - s0, (uint32_t *)(d_off + n_frames + 2 * parts + 1), ws));
+        rc = compress_impl(ctx, pt[g].plan, d_x + s0, compressor, bounded, max_error, sample_level, d_body, bound,
+                           d_off + pt[g].f0 + g, d_ch + pt[g].f0, d_err + pt[g].f0, ws, false,
+                           d_off + n_frames + parts + g);
+        if (rc) goto done;
+        lap("  part launches");
+    }
+    lap("h2d + launches");
+    FCHK(hipStreamSynchronize(ws));
+    lap("kernel tail");
+    {
+        uint64_t tail[2] = {0, 0};  // records' end, non-finite flag
+        FCHK(hipMemcpy(tail, d_off + n_frames + 2 * parts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        total = tail[0];
+        if (nonfinite) *nonfinite = (tail[1] & 0xffffffffull) != 0 ? 1 : 0;
+    }
+    *body_len = total;
+    if (out_alloc) {
+        body = (uint8_t *)malloc(head_room + total + 1);
+        if (!body) { rc = fail(ctx, ATSC_E_NOMEM, "compress_frames: output"); goto done; }
+        *out_alloc = body;
+        body += head_room;
+    } else if (total > body_cap) {
+        rc = fail(ctx, ATSC_E_CAPACITY, "compress_frames: body_cap");
+        goto done;
+    }
+    if (total) FCHK(hipMemcpy(body, d_body, total, hipMemcpyDeviceToHost));
+    if (rec_off) {
+        h_off.resize(n_frames + parts);
+        FCHK(hipMemcpy(h_off.data(), d_off, (n_frames + parts) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint64_t g = 0; g < parts; ++g)
+            for (uint64_t f = pt[g].f0; f < pt[g].f1; ++f) rec_off[f] = h_off[f + g];
+        rec_off[n_frames] = total;
+    }
+    lap("d2h records");
     if (chosen) FCHK(hipMemcpy(chosen, d_ch, n_frames, hipMemcpyDeviceToHost));
     if (err) FCHK(hipMemcpy(err, d_err, n_frames * sizeof(double), hipMemcpyDeviceToHost));
 #undef FCHK
 done:
+    if (rc) (void)hipStreamSynchronize(ws);  // nothing may still run on the blocks that go back to the pool
+    if (rc && out_alloc && *out_alloc) { free(*out_alloc); *out_alloc = nullptr; }
     pool_free(ctx, d_x);
     pool_free(ctx, d_body);
     pool_free(ctx, d_off);
     pool_free(ctx, d_ch);
     pool_free(ctx, d_err);
-    atsc_plan_destroy(plan);
     return rc;
+}
+extern "C" int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                                    uint64_t n_frames, int compressor, int bounded, float max_error,
+                                    int sample_level, uint8_t *body, uint64_t body_cap,
+                                    uint64_t *body_len, uint64_t *rec_off, uint8_t *chosen,
+                                    double *err)
+{
+    ATSC_API_BEGIN
+    return compress_frames_impl(ctx, samples, frame_off, n_frames, compressor, bounded, max_error, sample_level, body,
+                                body_cap, body_len, rec_off, chosen, err, nullptr);
+    ATSC_API_END
+}
+// atsc_compress_data's call (atsc_stream.cpp; declared in atsc_internal.h): the same, plus the device-side check
+// for samples that OptimizerPlan::clean_data would have dropped
+extern "C" int atsc_internal_compress_frames_scan(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                                                  uint64_t n_frames, int compressor, int bounded, float max_error,
+                                                  int sample_level, uint64_t head_room, uint8_t **out,
+                                                  uint64_t *body_len, uint64_t *rec_off, int *nonfinite)
+{
+    ATSC_API_BEGIN
+    if (!out) return ATSC_E_INVALID;
+    return compress_frames_impl(ctx, samples, frame_off, n_frames, compressor, bounded, max_error, sample_level, nullptr,
+                                0, body_len, rec_off, nullptr, nullptr, nonfinite, head_room, out);
     ATSC_API_END
 }
 
@@ -1305,6 +1498,8 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
     H.class_count.assign(N_CLASSES, 0);
     H.class_lds.assign(N_CLASSES, 0);
     uint64_t out_off = 0;
+    uint32_t last_n = 0, last_pi = 0;
+    if (has_count) { H.frames.reserve(declared); H.cls.reserve(declared); }
     while (has_count ? H.frames.size() < declared : pos < body_len) {
         HostRecord hr;
         if (!host_next_record(body, body_len, pos, hr)) { *why = "dplan_create: truncated frame record"; return ATSC_E_FORMAT; }
@@ -1322,14 +1517,20 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
         if (nout == 0) { *why = "dplan_create: frame sample count"; return ATSC_E_FORMAT; }
         if (nout > MAX_FRAME) { *why = "dplan_create: frame longer than 131072 samples"; return ATSC_E_UNSUPPORTED; }
         const uint32_t n = (uint32_t)nout;
-        auto it = H.tabs.by_n.find(n);
         uint32_t pi;
-        if (it == H.tabs.by_n.end()) {
-            int rc = build_plan_entry(n, H.tabs, tw_by_L, false, true);
-            if (rc) { *why = "dplan_create: plan entry"; return rc; }
-            pi = H.tabs.by_n[n];
+        if (n == last_n) {  // streams are runs of equal frame lengths: skip the table lookup
+            pi = last_pi;
         } else {
-            pi = it->second;
+            auto it = H.tabs.by_n.find(n);
+            if (it == H.tabs.by_n.end()) {
+                int rc = build_plan_entry(n, H.tabs, tw_by_L, false, true);
+                if (rc) { *why = "dplan_create: plan entry"; return rc; }
+                pi = H.tabs.by_n[n];
+            } else {
+                pi = it->second;
+            }
+            last_n = n;
+            last_pi = pi;
         }
         const DevPlan &dp = H.tabs.plans[pi];
         const int c = class_of(n, dp.L);
@@ -1466,13 +1667,23 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
 static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
                                   double *out, uint64_t out_cap, double **out_alloc, uint64_t *out_n)
 {
+    static const bool trace = getenv("ATSC_TRACE_HOST") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[decompress] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     atsc_dplan *dp = nullptr;
     int rc = atsc_dplan_create(ctx, body, body_len, has_count, &dp);
+    lap("dplan_create");
     if (rc) return rc;
     *out_n = dp->n_samples;
     double *host = out;
     if (!out) {
-        host = (double *)malloc((dp->n_samples ? dp->n_samples : 1) * sizeof(double));
+        // (big_alloc: the block the caller released last is handed out again, resident pages and all)
+        host = (double *)big_alloc((dp->n_samples ? dp->n_samples : 1) * sizeof(double));
         if (!host) { atsc_dplan_destroy(dp); return fail(ctx, ATSC_E_NOMEM, "decompress_frames: output"); }
     } else if (dp->n_samples > out_cap) {
         atsc_dplan_destroy(dp);
@@ -1489,20 +1700,26 @@ static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t b
     } while (0)
     FCHK(pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(body_len, 16)));
     FCHK(pool_alloc(ctx, (void **)&d_out, dp->n_samples * sizeof(double)));
+    lap("alloc");
     FCHK(hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice));
+    lap("h2d records");
     rc = atsc_decompress_plan_dev(ctx, dp, d_body, d_out, nullptr);
     if (rc) goto done;
     FCHK(hipStreamSynchronize(nullptr));
+    lap("kernels");
     FCHK(hipMemcpy(&status, dp->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (status) { rc = fail(ctx, ATSC_E_FORMAT, "decompress_frames: malformed payload"); goto done; }
+    lap("status");
     FCHK(hipMemcpy(host, d_out, dp->n_samples * sizeof(double), hipMemcpyDeviceToHost));
+    lap("d2h samples");
 #undef FCHK
 done:
     pool_free(ctx, d_body);
     pool_free(ctx, d_out);
     atsc_dplan_destroy(dp);
+    lap("free + destroy");
     if (!out) {
-        if (rc) free(host);
+        if (rc) atsc_free(host);
         else *out_alloc = host;
     }
     return rc;

@@ -217,6 +217,25 @@ static inline bool host_next_record(const uint8_t *b, uint64_t len, uint64_t &po
 
 }  // namespace atsc
 
+// Large host results handed to the caller (decoded samples) come from big_alloc and go back through atsc_free
+// -> big_release: the block released last is kept and handed out again when the next result is about the same
+// size.  A fresh allocation of 84 MB is untouched address space whose pages fault in one by one during the
+// device-to-host copy (milliseconds, more than the copy itself); a recycled block is resident.  At most one
+// block (up to BIG_KEEP_MAX bytes) is held.
+namespace atsc {
+void *big_alloc(size_t bytes);
+bool big_release(void *p);  // true: p was a big_alloc block and has been taken care of
+}  // namespace atsc
+
+// atsc_compress_frames with the output allocated by the library once its length is known (*out: malloc'd,
+// head_room bytes left free in front of the records) and, when nonfinite != NULL, a device-side flag for NaN /
+// infinite samples (atsc_compress_data's clean_data check)
+struct atsc_ctx;
+extern "C" int atsc_internal_compress_frames_scan(atsc_ctx *ctx, const double *samples, const uint64_t *frame_off,
+                                                  uint64_t n_frames, int compressor, int bounded, float max_error,
+                                                  int sample_level, uint64_t head_room, uint8_t **out,
+                                                  uint64_t *body_len, uint64_t *rec_off, int *nonfinite);
+
 // test hook (tests/asan): the host half of atsc_dplan_create on untrusted bytes, no GPU needed
 extern "C" int atsc_internal_dplan_parse(const uint8_t *body, uint64_t body_len, int has_count,
                                          uint64_t *n_frames, uint64_t *n_samples);

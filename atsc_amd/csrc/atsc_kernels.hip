@@ -25,6 +25,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include "atsc_device.h"
@@ -1525,8 +1526,11 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     const DevFrame *__restrict__ frames, const DevResult *__restrict__ res, uint64_t n_frames,
     const uint32_t *__restrict__ local, const uint64_t *__restrict__ blocksum,
     const uint8_t *__restrict__ slots, uint8_t *__restrict__ body, uint64_t body_cap,
-    uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen, double *__restrict__ err)
+    uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen, double *__restrict__ err,
+    const uint64_t *__restrict__ chain_in, uint64_t *__restrict__ chain_out)
 {
+    // chain_in / chain_out (optional): this call's records start at *chain_in in `body` and their end goes to
+    // *chain_out -- consecutive calls of one stream lay their records end to end (atsc_compress_frames)
     const uint64_t f = (uint64_t)blockIdx.x * EMIT_FRAMES + (threadIdx.x / EMIT_LANES);
     const uint32_t lane = threadIdx.x & 63, l8 = threadIdx.x & (EMIT_LANES - 1);
     const uint32_t chunk = (uint32_t)(((uint64_t)blockIdx.x * EMIT_FRAMES) / PACK_CHUNK);
@@ -1539,6 +1543,7 @@ __global__ __launch_bounds__(256) void k_pack_emit(
     } else {
         base = blocksum[chunk];
     }
+    if (chain_in) base += *chain_in;
     if (f >= n_frames) return;
     const DevFrame fr = frames[f];
     const DevResult r = res[f];
@@ -1548,7 +1553,10 @@ __global__ __launch_bounds__(256) void k_pack_emit(
         rec_off[f] = off;
         if (chosen) chosen[f] = (uint8_t)r.chosen;
         if (err) err[f] = r.err;
-        if (f == n_frames - 1) rec_off[n_frames] = off + hl + r.len;
+        if (f == n_frames - 1) {
+            rec_off[n_frames] = off + hl + r.len;
+            if (chain_out) *chain_out = off + hl + r.len;
+        }
     }
     if (off + hl + r.len > body_cap) return;  // caller sized d_body too small; rec_off tells
     uint8_t *dst = body + off;
@@ -1625,8 +1633,7 @@ extern "C" int atsc_internal_heap_order(const float *norms, uint32_t bins, uint3
     if (hipMalloc((void **)&d_n, bins * sizeof(float)) != hipSuccess) return ATSC_E_HIP;
     if (hipMalloc((void **)&d_o, (k ? k : 1) * sizeof(uint32_t)) == hipSuccess &&
         hipMemcpy(d_n, norms, bins * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
-        (lds <= 48 * 1024 || hipFuncSetAttribute((const void *)atsc::k_test_heap_order,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)) {
+        (lds <= 48 * 1024 || atsc::ensure_dyn_lds((const void *)atsc::k_test_heap_order, lds) == hipSuccess)) {
         hipLaunchKernelGGL(atsc::k_test_heap_order, dim3(1), dim3(64), lds, nullptr, d_n, bins, k, d_o);
         if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
             hipMemcpy(order, d_o, k * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1637,6 +1644,29 @@ extern "C" int atsc_internal_heap_order(const float *norms, uint32_t bins, uint3
     return rc;
 }
 namespace atsc {
+
+// --------------------------------------------------------------------------------------------
+// OptimizerPlan::clean_data (optimizer/mod.rs:64-71) drops NaN and infinite samples before chunking.  A series
+// almost never holds one, and finding out on the host means a pass over all of it at one core's memory speed
+// (tens of milliseconds for 84 MB that was not in cache); here the samples are on their way to the GPU anyway:
+// the flag is raised on the device, and only a series that does hold such a sample takes the host's cleaning pass.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nonfinite_flag(const double *__restrict__ x, uint64_t n, uint32_t *__restrict__ flag)
+{
+    uint32_t bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t b = (uint64_t)__double_as_longlong(x[i]);
+        bad |= ((b & 0x7ff0000000000000ull) == 0x7ff0000000000000ull) ? 1u : 0u;
+    }
+    if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t launch_nonfinite_flag(const double *x, uint64_t n, uint32_t *flag, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 2047) / 2048, 4096);
+    hipLaunchKernelGGL(k_nonfinite_flag, dim3(grid), dim3(256), 0, s, x, n, flag);
+    return hipGetLastError();
+}
 
 // --------------------------------------------------------------------------------------------
 // launchers
@@ -1656,8 +1686,7 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
     }();
     lds += lds_pad;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dyn_lds((const void *)kern, lds);
         if (e != hipSuccess) return e;
     }
     // ev0 / ev1 (optional) take the start / end timestamps of this dispatch itself: no separate
@@ -1719,8 +1748,10 @@ hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const do
 hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_frames,
                        uint32_t *local, uint64_t *blocksum, const uint8_t *slots, uint8_t *body,
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
-                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s)
+                       const uint32_t *big_ids, uint32_t n_big, hipStream_t s, uint64_t *chain)
 {
+    const uint64_t *chain_in = chain;
+    uint64_t *chain_out = chain ? chain + 1 : nullptr;
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
@@ -1729,18 +1760,18 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
     if (nb <= 64) {
         if (big)
             hipLaunchKernelGGL((k_pack_emit<true, true>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                               slots, body, body_cap, rec_off, chosen, err);
+                               slots, body, body_cap, rec_off, chosen, err, chain_in, chain_out);
         else
             hipLaunchKernelGGL((k_pack_emit<true, false>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                               slots, body, body_cap, rec_off, chosen, err);
+                               slots, body, body_cap, rec_off, chosen, err, chain_in, chain_out);
     } else {
         hipLaunchKernelGGL(k_pack_scan2, dim3(1), dim3(256), 0, s, blocksum, nb);
         if (big)
             hipLaunchKernelGGL((k_pack_emit<false, true>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                               slots, body, body_cap, rec_off, chosen, err);
+                               slots, body, body_cap, rec_off, chosen, err, chain_in, chain_out);
         else
             hipLaunchKernelGGL((k_pack_emit<false, false>), eg, dim3(256), 0, s, frames, res, n_frames, local, blocksum,
-                               slots, body, body_cap, rec_off, chosen, err);
+                               slots, body, body_cap, rec_off, chosen, err, chain_in, chain_out);
     }
     if (big)
         hipLaunchKernelGGL(k_pack_emit_big, dim3(n_big), dim3(256), 0, s, frames, res, big_ids, rec_off, slots,

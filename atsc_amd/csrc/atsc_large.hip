@@ -804,9 +804,16 @@ __global__ __launch_bounds__(PT) void k_large_pre2(const double *__restrict__ sa
         if (r < nseq) X[(r0 + r) + f.M1 * k2] = R[r * ld + k2];
     }
 }
-// untangle (even L) + norm bits + non-zero count + empty admitted spectrum, 256 bins per workgroup
-constexpr int PT3 = 256;
-__global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ samples,
+// Pass 2 of the encoder's pre-pass with the untangle step, the norms and the zero count fused in (k_large_pre2 +
+// the former k_large_pre3 in one kernel): the row transforms' results never go to memory as Z.  Untangling bin
+// k = k1 + M1 k2 needs Z[k] and Z[M - k], and M - k = (M1 - k1) + M1 (M2 - 1 - k2): the partner lives in the
+// mirrored row at the mirrored column.  So a workgroup takes FBH rows a0 .. a0 + FBH - 1 TOGETHER WITH their
+// mirrors M1 - a (2 FBH rows in LDS, as many as k_large_pre2's tile); row 0 (its own mirror, columns k2 and
+// M2 - k2, plus bin M) and, for even M1, the middle row go to workgroup 0.  Arithmetic as in fft_untangle (atsc_kernels.hip),
+// operation for operation.  The spectrum lands in buffer A (buffer B still holds pass 1's output while other
+// workgroups read it).
+constexpr uint32_t FBH = FB / 2;
+__global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ samples,
                                                     const DevFrame *__restrict__ frames,
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
@@ -814,43 +821,108 @@ __global__ __launch_bounds__(PT3) void k_large_pre3(const double *__restrict__ s
                                                     unsigned char *__restrict__ ws_base, uint64_t ws_stride,
                                                     int sparse_inv)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevPlan *P;
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
-    const uint32_t k = blockIdx.x * PT3 + threadIdx.x;
-    if (blockIdx.x * PT3 >= f.bins) return;
+    const uint32_t M1 = f.M1, M2 = f.M2, M = f.M;
+    const uint32_t half_pairs = (M1 - 1) / 2;  // rows 1 .. half_pairs pair with M1 - 1 .. M1 - half_pairs
+    uint32_t a0 = 0, cnt = 0, nrow;
+    if (blockIdx.x == 0) {
+        nrow = (M1 % 2 == 0 && M1 >= 2) ? 2u : 1u;  // row 0, and the self-mirrored row M1 / 2
+    } else {
+        const uint32_t first = (blockIdx.x - 1) * FBH;
+        if (first >= half_pairs) return;
+        a0 = 1 + first;
+        cnt = min(FBH, half_pairs - first);
+        nrow = 2 * cnt;
+    }
+    auto row_of = [&](uint32_t r) -> uint32_t {
+        if (blockIdx.x == 0) return r == 0 ? 0u : M1 / 2;
+        return r < cnt ? a0 + r : M1 - a0 - cnt + 1 + (r - cnt);  // both groups ascending
+    };
     const LargeWs lay = large_ws_layout(f.n, f.L, P->kcap);
-    const float2 *Z = (const float2 *)(f.ws + lay.o_a);
-    float2 *spec = f.half ? (float2 *)(f.ws + lay.o_b) : (float2 *)(f.ws + lay.o_a);
+    const float2 *Y = (const float2 *)(f.ws + lay.o_b);
+    float2 *spec = (float2 *)(f.ws + lay.o_a);
     uint32_t *nbits = (uint32_t *)(f.ws + lay.o_nb);
     float2 *Xs = (float2 *)(f.ws + lay.o_x);
     const float2 *tw = twpool + P->tw_off;
-    uint32_t zeros = 0;
-    if (k < f.bins) {
-        float2 z;
-        if (f.half) {  // see fft_untangle (atsc_kernels.hip); bins = M + 1
-            const uint32_t M = f.M;
-            const float2 zk = Z[k == M ? 0 : k];
-            const float2 zm = Z[k == 0 ? 0 : M - k];
-            const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
-            const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);
-            const float2 t = cmulc(make_float2(b.y, -b.x), tw[k]);
-            z = make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
-            spec[k] = z;
-        } else {
-            z = Z[k];
+    const uint32_t ld = M2 + 1;
+    float2 *T = (float2 *)smem, *U = T + FB * ld, *w2 = U + FB * ld;
+    for (uint32_t e = threadIdx.x; e < M2; e += PT) w2[e] = tw[e * (M1 * f.sc)];
+    const uint32_t mg_m2 = (uint32_t)(0x100000000ull / M2) + 1u;
+    {
+        constexpr uint32_t PU = (F4_MAX * FB + PT - 1) / PT;
+        float2 v[PU];
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            v[u] = make_float2(0.0f, 0.0f);
+            if (w < nrow * M2) {
+                const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * M2;
+                v[u] = Y[row_of(r) * M2 + n2];
+            }
         }
-        nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
-        zeros = (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
-        if (!(sparse_inv && P->sp_mf)) Xs[k] = make_float2(0.0f, 0.0f);  // the dense ladder's admitted spectrum
+#pragma unroll
+        for (uint32_t u = 0; u < PU; ++u) {
+            const uint32_t w = threadIdx.x + u * PT;
+            if (w < nrow * M2) {
+                const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * M2;
+                T[r * ld + n2] = v[u];
+            }
+        }
     }
-    // fft.rs:249-252 needs the number of non-zero bins; zero bins are the rare ones, so they are what
-    // gets counted (a same-address atomic per wavefront serialised ~1100 deep per frame otherwise)
+    __syncthreads();
+    const float2 *R = lds_fft<false>(T, U, w2, M2, nrow, 1, ld, PT);
+    const bool dense = !(sparse_inv && P->sp_mf);
+    uint32_t zeros = 0;
+    auto finish = [&](uint32_t k, float2 z) {
+        spec[k] = z;
+        nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+        zeros += (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
+        if (dense) Xs[k] = make_float2(0.0f, 0.0f);  // the dense ladder's admitted spectrum
+    };
+    // (every twiddle load of a thread is issued before the first one is used: a dependent global load per bin
+    // otherwise, with only two workgroups on the CU to hide it)
+    constexpr uint32_t PU2 = (F4_MAX * FB + PT - 1) / PT;
+    float2 twk[PU2];
+#pragma unroll
+    for (uint32_t u = 0; u < PU2; ++u) {
+        const uint32_t w = threadIdx.x + u * PT;
+        const uint32_t r = w & (FB - 1), k2 = w >> 4;
+        twk[u] = make_float2(1.0f, 0.0f);
+        if (w < M2 * FB && r < nrow && f.half) twk[u] = tw[row_of(r) + M1 * k2];
+    }
+    auto untangle = [&](float2 zk, float2 zm, float2 wk) -> float2 {  // see fft_untangle (atsc_kernels.hip)
+        const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+        const float2 b = make_float2(zk.x - zm.x, zk.y + zm.y);
+        const float2 t = cmulc(make_float2(b.y, -b.x), wk);
+        return make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+    };
+#pragma unroll
+    for (uint32_t u = 0; u < PU2; ++u) {
+        const uint32_t w = threadIdx.x + u * PT;
+        const uint32_t r = w & (FB - 1), k2 = w >> 4;
+        if (w >= M2 * FB || r >= nrow) continue;
+        const uint32_t k1 = row_of(r), k = k1 + M1 * k2;
+        const float2 zk = R[r * ld + k2];
+        if (!f.half) {  // complex transform of the real signal: bins 0 .. L / 2 are kept
+            if (k < f.bins) finish(k, zk);
+            else spec[k] = zk;
+            continue;
+        }
+        float2 zm;
+        if (blockIdx.x == 0 && r == 0) zm = R[(k2 == 0) ? 0 : (M2 - k2)];           // row 0: columns k2 <-> M2 - k2
+        else if (blockIdx.x == 0) zm = R[ld + (M2 - 1 - k2)];                        // the middle row mirrors itself
+        else zm = R[(nrow - 1 - r) * ld + (M2 - 1 - k2)];
+        finish(k, untangle(zk, zm, twk[u]));
+        if (k == 0) finish(M, untangle(zk, zk, tw[M]));  // bin M: Z[0] with Z[0]
+    }
+    // fft.rs:249-252 needs the number of non-zero bins; zero bins are the rare ones, so they are what gets counted
     if (__ballot(zeros != 0)) {
         zeros = wave_sum_u32(zeros);
         if ((threadIdx.x & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
     }
 }
-
 // --------------------------------------------------------------------------------------------
 // k_compress_large
 // --------------------------------------------------------------------------------------------
@@ -862,7 +934,7 @@ constexpr uint32_t LKEYS_MAX = 16384;  // LDS sort capacity (kcap of a 131072-sa
 // per-frame kernel instead of inside it on the frame's one CU.
 // --------------------------------------------------------------------------------------------
 constexpr uint32_t LCH = 4096;  // samples per chunk
-struct LargeStats {             // at o_cnt; `zeros` is the pre-pass's count of zero bins (k_large_pre3)
+struct LargeStats {             // at o_cnt; `zeros` is the pre-pass's count of zero bins (k_large_pre23)
     uint32_t zeros, frac, runs, ibytes;
     unsigned long long kmin, kmax;  // min / max as order-preserving integer keys (integer atomics combine chunks)
 };
@@ -1649,7 +1721,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             // ---- forward transform of the padded f32 signal ----
             float2 *spec;
             if (prm.prefft) {
-                spec = P.half ? B : A;  // k_large_pre1..3 left the spectrum, nbits, Xs = 0 and the count
+                spec = A;  // k_large_pre1 / k_large_pre23 left the spectrum, nbits, Xs = 0 and the count
             } else if (P.half) {
                 float *Af = (float *)A;
                 for (uint32_t j = tid; j < L; j += T) Af[j] = (float)gpad(j);
@@ -2225,7 +2297,7 @@ __global__ __launch_bounds__(LT) void k_large_trip_tiles(
     for (uint32_t e = tid; e < Md; e += LT) sl.wd[e] = tw[e * (L / Md)];
     __syncthreads();
     // the list sits in the FFT buffer that does not hold the spectrum (see k_compress_large: spec / work)
-    const SpEnt *zl = (const SpEnt *)(ws + (P.half ? lay.o_a : lay.o_b));
+    const SpEnt *zl = (const SpEnt *)(ws + lay.o_b);
     const double mxd = (double)(float)fst->smax, mnd = (double)(float)fst->smin;
     const float Lf = (float)L;
     double s = 0.0;
@@ -2255,8 +2327,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const LargePre *pre)
 {
     const uint32_t lds = 384 + 1024 + 64 + max(8 * LKEYS_MAX, SP_LDS_BYTES);
-    hipError_t e = hipFuncSetAttribute((const void *)k_compress_large<0>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dyn_lds((const void *)k_compress_large<0>, lds);
     if (e != hipSuccess) return e;
     KParams kp = prm;
     kp.prefft = (pre && pre->tiles1) ? 1u : 0u;
@@ -2267,11 +2338,11 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     const uint32_t lds_tiles = SP_LDS_BYTES + 512;
     kp.prestats = (split && pre->chunks_n) ? 1u : 0u;
     if (split) {
-        e = hipFuncSetAttribute((const void *)k_compress_large<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dyn_lds((const void *)k_compress_large<1>, lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)k_compress_large<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dyn_lds((const void *)k_compress_large<2>, lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)k_large_trip_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles);
+        e = ensure_dyn_lds((const void *)k_large_trip_tiles, lds_tiles);
         if (e != hipSuccess) return e;
     }
     // tile buffers of a pre-pass workgroup: two of FB x (sub-transform length [+ 1]) points + its twiddles
@@ -2279,9 +2350,9 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     if (kp.prefft) {
         lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
         lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
-        e = hipFuncSetAttribute((const void *)k_large_pre1<DevFrame, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        e = ensure_dyn_lds((const void *)k_large_pre1<DevFrame, false>, lds1);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)k_large_pre2<DevFrame, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        e = ensure_dyn_lds((const void *)k_large_pre23, lds2);
         if (e != hipSuccess) return e;
     }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
@@ -2299,10 +2370,9 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         if (kp.prefft) {
             hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames,
                                ids + b0, plans, twpool, ws, ws_stride);
-            hipLaunchKernelGGL((k_large_pre2<DevFrame, false>), dim3(pre->tiles2, nb), dim3(PT), lds2, s, samples, frames,
-                               ids + b0, plans, twpool, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_pre3, dim3(pre->chunks, nb), dim3(PT3), 0, s, samples, frames, ids + b0,
-                               plans, twpool, ws, ws_stride, (int)kp.sparse_inv);
+            const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
+            hipLaunchKernelGGL(k_large_pre23, dim3(tiles23, nb), dim3(PT), lds2, s, samples, frames, ids + b0, plans,
+                               twpool, ws, ws_stride, (int)kp.sparse_inv);
         }
         if (split) {
             hipLaunchKernelGGL(k_compress_large<1>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
@@ -2819,20 +2889,19 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
     const bool split = pre && pre->tiles1 && !sparse;
     hipError_t e;
     if (sparse && sp_tiles) {
-        e = hipFuncSetAttribute((const void *)k_decompress_large_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)SP_LDS_BYTES);
+        e = ensure_dyn_lds((const void *)k_decompress_large_tiles, SP_LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     uint32_t lds1 = 0, lds2 = 0;
     if (split) {
         lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
         lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
-        e = hipFuncSetAttribute((const void *)k_large_pre1<DevDFrame, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        e = ensure_dyn_lds((const void *)k_large_pre1<DevDFrame, true>, lds1);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)k_large_pre2<DevDFrame, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        e = ensure_dyn_lds((const void *)k_large_pre2<DevDFrame, true>, lds2);
         if (e != hipSuccess) return e;
     } else {
-        e = hipFuncSetAttribute((const void *)k_decompress_large<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dyn_lds((const void *)k_decompress_large<0>, lds);
         if (e != hipSuccess) return e;
     }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {

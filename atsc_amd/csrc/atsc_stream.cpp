@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <thread>
@@ -64,7 +65,51 @@ struct atsc_stream {
     std::vector<Item> items;
 };
 
-extern "C" void atsc_free(void *p) { free(p); }
+namespace atsc {
+static std::mutex g_big_mu;
+static std::map<void *, size_t> g_big_live;   // blocks handed out by big_alloc
+static void *g_big_kept = nullptr;            // the block released last, still resident
+static size_t g_big_kept_size = 0;
+static const size_t BIG_MIN = 8u << 20, BIG_KEEP_MAX = 2ull << 30;
+void *big_alloc(size_t bytes)
+{
+    if (bytes < BIG_MIN) return malloc(bytes ? bytes : 1);
+    std::lock_guard<std::mutex> g(g_big_mu);
+    void *p = nullptr;
+    size_t sz = bytes;
+    if (g_big_kept && g_big_kept_size >= bytes && g_big_kept_size <= 2 * bytes) {
+        p = g_big_kept;
+        sz = g_big_kept_size;
+        g_big_kept = nullptr;
+        g_big_kept_size = 0;
+    } else {
+        p = malloc(bytes);
+    }
+    if (p) g_big_live[p] = sz;
+    return p;
+}
+bool big_release(void *p)
+{
+    std::lock_guard<std::mutex> g(g_big_mu);
+    auto it = g_big_live.find(p);
+    if (it == g_big_live.end()) return false;
+    const size_t sz = it->second;
+    g_big_live.erase(it);
+    if (sz <= BIG_KEEP_MAX && sz >= g_big_kept_size) {  // keep the larger of the two
+        if (g_big_kept) free(g_big_kept);
+        g_big_kept = p;
+        g_big_kept_size = sz;
+    } else {
+        free(p);
+    }
+    return true;
+}
+}  // namespace atsc
+
+extern "C" void atsc_free(void *p)
+{
+    if (p && !atsc::big_release(p)) free(p);
+}
 
 extern "C" int atsc_stream_new(atsc_ctx *ctx, atsc_stream **out)
 {
@@ -133,25 +178,22 @@ static int flush(atsc_stream *s)
         std::vector<uint64_t> off(idx.size() + 1, 0);
         for (size_t k = 0; k < idx.size(); ++k) off[k + 1] = off[k] + s->items[idx[k]].chunk.size();
         std::vector<double> flat(off.back());
-        uint64_t cap = 0;
         for (size_t k = 0; k < idx.size(); ++k) {
             const std::vector<double> &c = s->items[idx[k]].chunk;
             memcpy(flat.data() + off[k], c.data(), c.size() * sizeof(double));
-            cap += atsc_payload_bound_bytes(c.size()) + 16;
         }
-        // worst-case capacity, never touched beyond the bytes that come back: no zero fill
-        std::unique_ptr<uint8_t[]> body(new (std::nothrow) uint8_t[cap ? cap : 1]);
-        if (!body) return ATSC_E_NOMEM;
+        uint8_t *body = nullptr;
         std::vector<uint64_t> rec_off(idx.size() + 1);
         uint64_t blen = 0;
         const Item &first = s->items[idx[0]];
-        int rc = atsc_compress_frames(s->ctx, flat.data(), off.data(), idx.size(), first.compressor,
-                                      first.bounded, first.max_error, first.level, body.get(), cap, &blen,
-                                      rec_off.data(), nullptr, nullptr);
+        int rc = atsc_internal_compress_frames_scan(s->ctx, flat.data(), off.data(), idx.size(), first.compressor,
+                                                    first.bounded, first.max_error, first.level, 0, &body, &blen,
+                                                    rec_off.data(), nullptr);
         if (rc) return rc;
+        std::unique_ptr<uint8_t, void (*)(void *)> body_owner(body, free);
         for (size_t k = 0; k < idx.size(); ++k) {
             Item &it = s->items[idx[k]];
-            it.record.assign(body.get() + rec_off[k], body.get() + rec_off[k + 1]);
+            it.record.assign(body + rec_off[k], body + rec_off[k + 1]);
             it.pending = false;
             std::vector<double>().swap(it.chunk);
         }
@@ -247,18 +289,18 @@ extern "C" int atsc_stream_decompress(atsc_stream *s, double **out, uint64_t *n)
     if (s->items.empty()) { *out = (double *)malloc(8); return *out ? ATSC_OK : ATSC_E_NOMEM; }
     // Noop frames decode to their stored count, not sample_count (noop.rs:79-83): ask the decoder
     uint64_t cap = samples + 16;
-    double *buf = (double *)malloc(cap * sizeof(double));
+    double *buf = (double *)atsc::big_alloc(cap * sizeof(double));
     if (!buf) return ATSC_E_NOMEM;
     uint64_t got = 0;
     rc = atsc_decompress_frames(s->ctx, body.data(), body.size(), 0, buf, cap, &got);
     if (rc == ATSC_E_CAPACITY) {
-        free(buf);
+        atsc_free(buf);
         cap = got;
-        buf = (double *)malloc((cap ? cap : 1) * sizeof(double));
+        buf = (double *)atsc::big_alloc((cap ? cap : 1) * sizeof(double));
         if (!buf) return ATSC_E_NOMEM;
         rc = atsc_decompress_frames(s->ctx, body.data(), body.size(), 0, buf, cap, &got);
     }
-    if (rc) { free(buf); return rc; }
+    if (rc) { atsc_free(buf); return rc; }
     *out = buf;
     *n = got;
     return ATSC_OK;
@@ -276,86 +318,52 @@ extern "C" int atsc_compress_data(atsc_ctx *ctx, const double *data, uint64_t n,
     *bro = nullptr;
     *len = 0;
     if (compressor < 0 || compressor > 6 || sample_level < 0 || sample_level > 6) return ATSC_E_INVALID;
-    // OptimizerPlan::plan drops NaN and infinite samples (optimizer/mod.rs:47-49); the copy is only
-    // made when there is something to drop
-    // Long inputs are scanned by a helper thread while this one already sends the samples to the GPU and
-    // compresses them as they are (the scan reads 8 B per sample at host-memory speed, about what the
-    // pageable copy takes); if the scan does find something to drop, that result is discarded and the
-    // cleaned copy goes through.
-    auto has_nonfinite = [](const double *p, uint64_t cnt) {
-        for (uint64_t b = 0; b < cnt; b += 4096) {
-            const uint64_t e = std::min<uint64_t>(b + 4096, cnt);
-            uint64_t bad = 0;
-            for (uint64_t i = b; i < e; ++i) {
-                uint64_t bits;
-                memcpy(&bits, p + i, 8);
-                bad |= ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull) ? 1u : 0u;
-            }
-            if (bad) return true;
-        }
-        return false;
-    };
-    bool dirty = false;
-    std::thread scanner;
-    struct Joiner {  // an early return or an exception must not destroy a joinable thread (std::terminate)
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{scanner};
-    const bool overlap = n >= (1u << 20);
-    if (overlap) scanner = std::thread([&] { dirty = has_nonfinite(data, n); });
-    else dirty = has_nonfinite(data, n);
+    // OptimizerPlan::plan drops NaN and infinite samples before it chunks (optimizer/mod.rs:47-49,64-71).  A
+    // series almost never holds one, and a host pass that finds out costs one core's memory speed over all of it
+    // (tens of milliseconds for 84 MB).  So the samples go to the GPU as they are, the check runs there beside the
+    // codecs (k_nonfinite_flag), and only when it fires is the result thrown away and the series compressed
+    // again from a cleaned copy.
     std::vector<double> clean;
     const double *src = data;
     uint64_t cn = n;
-    bool use_clean = !overlap && dirty;  // (with a scanner running, `dirty` is its to write until the join)
     for (int attempt = 0; attempt < 2; ++attempt) {
-    if (use_clean) {
-        clean.resize(n);
-        cn = atsc_clean_data(data, n, clean.data());
-        src = clean.data();
-    }
-    const uint64_t nch = atsc_chunk_sizes(cn, nullptr, 0);
-    if (nch == 0) {  // an empty stream: header + count 0 (data.rs:79-85)
-        if (scanner.joinable()) scanner.join();
-        uint8_t *buf = (uint8_t *)malloc(18);
-        if (!buf) return ATSC_E_NOMEM;
-        *len = atsc_bro_prefix(0, buf);
-        *bro = buf;
-        return ATSC_OK;
-    }
-    std::vector<uint64_t> sizes(nch), off(nch + 1, 0);
-    atsc_chunk_sizes(cn, sizes.data(), nch);
-    uint64_t cap = 0;
-    for (uint64_t c = 0; c < nch; ++c) {
-        off[c + 1] = off[c] + sizes[c];
-        cap += atsc_payload_bound_bytes(sizes[c]) + 16;
-    }
-    // main.rs:146-163: every chunk of the plan goes through the same call, bounded for the lossy
-    // codecs and Auto, plain otherwise -- one batch for the GPU, written behind the stream prefix
-    const bool lossy = compressor == ATSC_FFT || compressor == ATSC_POLYNOMIAL || compressor == ATSC_IDW ||
-                       compressor == ATSC_AUTO;                            // main.rs:150-162
-    const float max_error = lossy ? (float)error_pct / 100.0f : 0.0f;      // main.rs:157
-    uint8_t *buf = (uint8_t *)malloc(18 + cap);  // worst case; only the bytes produced are touched
-    if (!buf) { if (scanner.joinable()) scanner.join(); return ATSC_E_NOMEM; }
-    const uint64_t pre = atsc_bro_prefix(nch, buf);
-    uint64_t blen = 0;
-    int rc = atsc_compress_frames(ctx, src, off.data(), nch, compressor, lossy ? 1 : 0, max_error,
-                                  lossy ? sample_level : 0, buf + pre, cap, &blen, nullptr, nullptr, nullptr);
-    if (scanner.joinable()) {
-        scanner.join();
-        if (dirty) {  // compressed with samples the reference drops: again, from the cleaned copy
+        const uint64_t nch = atsc_chunk_sizes(cn, nullptr, 0);
+        if (nch == 0) {  // an empty stream: header + count 0 (data.rs:79-85)
+            uint8_t *buf = (uint8_t *)malloc(18);
+            if (!buf) return ATSC_E_NOMEM;
+            *len = atsc_bro_prefix(0, buf);
+            *bro = buf;
+            return ATSC_OK;
+        }
+        std::vector<uint64_t> sizes(nch), off(nch + 1, 0);
+        atsc_chunk_sizes(cn, sizes.data(), nch);
+        for (uint64_t c = 0; c < nch; ++c) off[c + 1] = off[c] + sizes[c];
+        // main.rs:146-163: every chunk of the plan goes through the same call, bounded for the lossy
+        // codecs and Auto, plain otherwise -- one batch for the GPU, written behind the stream prefix
+        const bool lossy = compressor == ATSC_FFT || compressor == ATSC_POLYNOMIAL || compressor == ATSC_IDW ||
+                           compressor == ATSC_AUTO;                            // main.rs:150-162
+        const float max_error = lossy ? (float)error_pct / 100.0f : 0.0f;      // main.rs:157
+        uint8_t prefix[18];
+        const uint64_t pre = atsc_bro_prefix(nch, prefix);
+        uint8_t *buf = nullptr;
+        uint64_t blen = 0;
+        int dirty = 0;
+        const int rc = atsc_internal_compress_frames_scan(ctx, src, off.data(), nch, compressor, lossy ? 1 : 0, max_error,
+                                                          lossy ? sample_level : 0, pre, &buf, &blen, nullptr, &dirty);
+        if (dirty && attempt == 0) {  // compressed with samples the reference drops: again, from the cleaned copy
             free(buf);
-            use_clean = true;
+            clean.resize(n);
+            cn = atsc_clean_data(data, n, clean.data());
+            src = clean.data();
             continue;
         }
+        if (rc) { free(buf); return rc; }
+        memcpy(buf, prefix, pre);
+        *bro = buf;
+        *len = pre + blen;
+        return ATSC_OK;
     }
-    if (rc) { free(buf); return rc; }
-    uint8_t *fit = (uint8_t *)realloc(buf, pre + blen);
-    *bro = fit ? fit : buf;
-    *len = pre + blen;
-    return ATSC_OK;
-    }
-    return ATSC_E_INVALID;  // not reached: the second attempt has no scanner left to send it round again
+    return ATSC_E_INVALID;  // not reached: a cleaned copy holds nothing left to drop
     ATSC_API_END
 }
 

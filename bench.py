@@ -177,7 +177,7 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
         rc = lib.atsc_compress_data(ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)), n, atsc_amd.AUTO, ERROR_PCT, 0,
                                     C.byref(bro), C.byref(ln))
         atsc_amd.capi.check(rc, ctx._h)
-        b = bytes(C.cast(bro, C.POINTER(C.c_uint8 * ln.value)).contents)
+        b = C.string_at(bro, ln.value)
         lib.atsc_free(bro)
         return b
 

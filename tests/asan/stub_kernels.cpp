@@ -33,9 +33,10 @@ hipError_t launch_order_by_cost(const uint32_t *, uint32_t *, const uint32_t *, 
 {
     return hipErrorNotSupported;
 }
+hipError_t launch_nonfinite_flag(const double *, uint64_t, uint32_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_pack(const DevFrame *, const DevResult *, uint64_t, uint32_t *, uint64_t *, const uint8_t *,
                        uint8_t *, uint64_t, uint64_t *, uint8_t *, double *, const uint32_t *, uint32_t,
-                       hipStream_t)
+                       hipStream_t, uint64_t *)
 {
     return hipErrorNotSupported;
 }
