@@ -283,6 +283,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
     const DevPlan &P = plans[fr.plan];
     constexpr bool FIX = FN != 0;
+    // The fixed-length instantiations are the production path: no diagnostics record, no phase stops, no
+    // sample-level trial (launch_class routes those calls to the table-driven instantiation).  Their
+    // bookkeeping would otherwise sit in scalar registers for the whole kernel.
+    constexpr bool LEAN = FIX;
     constexpr uint32_t cL = FIX ? cx_next_size(FIX ? FN : 1) : 0, cmf = (3 >= FN / 100) ? 3 : FN / 100;
     static_assert(!FIX || (FN >= 128 && cL <= 64 * W * SPL), "fixed-length instantiation");
     constexpr bool chalf = cL % 2 == 0;              // even L: packed real transform of length L / 2
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         bitdepth = fr_any ? 0u : bitdepth_of(maxi, mini);
     }
 
-    if (prm.debug_stop == 1) return;
+    if (!LEAN && prm.debug_stop == 1) return;
     atsc_frame_diag dg;
     dg.fft_size = dg.poly_size = dg.rle_size = 0xFFFFFFFFu;
     dg.fft_trips = dg.fft_k = dg.poly_trips = dg.poly_step = 0;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     dg.fft_err = dg.poly_err = 0.0;
 
     // ---- Constant: frame/mod.rs:82-88 (auto shortcut) or forced (constant.rs:135-139) ------
-    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && !prm.trial && smin == smax)) {
+    if (mode == ATSC_CONSTANT || (mode == ATSC_AUTO && (LEAN || !prm.trial) && smin == smax)) {
         if (tid == 0) {
             out[0] = 30;
             out[1] = (uint8_t)bitdepth;
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             res[fid].err = 0.0;
             res[fid].len = 2 + vb;
             res[fid].chosen = ATSC_CONSTANT;
-            if (diag) diag[fid] = dg;
+            if (!LEAN && diag) diag[fid] = dg;
             if (prm.cost) prm.cost[fid] = (uint32_t)min((unsigned long long)(clock64() - t_start) >> 6, 0xFFFFFFFFull);
         }
         return;
@@ -406,22 +410,22 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             res[fid].err = 0.0;
             res[fid].len = hdr + tot;
             res[fid].chosen = ATSC_NOOP;
-            if (diag) diag[fid] = dg;
+            if (!LEAN && diag) diag[fid] = dg;
         }
         return;
     }
 
     // frame/mod.rs:89-111: frames of at least COMPRESSION_SPEED[level] samples take the codec the
     // trial on their first COMPRESSION_SPEED[level] samples chose, whatever error it then reaches
-    if (mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
+    if (!LEAN && mode == ATSC_AUTO && prm.trial_res != nullptr && n >= prm.trial_min_n)
         mode = (int)prm.trial_res[fid].chosen;
 
-    if (prm.debug_stop == 2) return;
+    if (!LEAN && prm.debug_stop == 2) return;
     // per-lane share of the padded signal g (fft.rs:184-204): lane owns j = tid + m*T.  Filled below,
     // once it is known that a ladder will run at all.
     double g[SPL], inv[SPL];
 
-    if (prm.debug_stop == 3) return;
+    if (!LEAN && prm.debug_stop == 3) return;
     // =========================================================================================
     // Candidates.  frame/mod.rs:113-147 keeps the smallest payload among the candidates whose error
     // passes `err <= max_error`, the first of [FFT, Polynomial, RLE] on ties.  Every ladder's payload
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
-    if (prm.debug_stop == 10) return;
+    if (!LEAN && prm.debug_stop == 10) return;
     // A payload below 19 bytes (FFT with one bin; Polynomial needs at least 23) already beats both
     // ladders: skip loading their operands.
     if (!(prune && best_size < 19)) {
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
-    if (prm.debug_stop == 11) return;
+    if (!LEAN && prm.debug_stop == 11) return;
     // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
     bool poly_first = false;
     if (prune && run_fft && run_poly && smax != smin) {
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     };
 
     if (poly_first) eval_poly();
-    if (prm.debug_stop == 13) return;
+    if (!LEAN && prm.debug_stop == 13) return;
     // =========================================================================================
     // FFT candidate: fft.rs:288-362
     // =========================================================================================
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 __syncthreads();
                 spec = fft_forward<W>(P, A, B, tw);
             }
-            if (prm.debug_stop == 4) return;
+            if (!LEAN && prm.debug_stop == 4) return;
             // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
             // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
             // and the next bin is pulled by two wavefront reductions when the ladder asks for it;
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 }
             }
 
-            if (prm.debug_stop == 5) return;
+            if (!LEAN && prm.debug_stop == 5) return;
             bool fft_pruned = false;
             float acc[SPL];
 #pragma unroll
@@ -1173,9 +1177,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
 
 
-    if (prm.debug_stop == 14) return;
+    if (!LEAN && prm.debug_stop == 14) return;
     if (!poly_first) eval_poly();
-    if (prm.debug_stop == 15) return;
+    if (!LEAN && prm.debug_stop == 15) return;
 
     // ---- RLE with many runs: exact size only if its bound can still win ----
     if (run_rle && rle_pending) {
@@ -1216,7 +1220,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
     dg.rle_size = rle_size;
 
-    if (prm.debug_stop == 8) return;
+    if (!LEAN && prm.debug_stop == 8) return;
     // =========================================================================================
     // selection: frame/mod.rs:113-147
     // =========================================================================================
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     // emit the chosen payload into the frame's slot
     // =========================================================================================
     uint32_t out_len = 0;
-    if (prm.trial) {
+    if (!LEAN && prm.trial) {
         if (tid == 0) {
             res[fid].err = chosen_err;
             res[fid].len = 0;
@@ -1368,7 +1372,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         res[fid].err = chosen_err;
         res[fid].len = out_len;
         res[fid].chosen = (uint32_t)chosen;
-        if (diag) diag[fid] = dg;
+        if (!LEAN && diag) diag[fid] = dg;
         if (prm.cost) prm.cost[fid] = (uint32_t)min((unsigned long long)(clock64() - t_start) >> 6, 0xFFFFFFFFull);
     }
 }
@@ -1707,7 +1711,8 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     // uniform launches of the power-of-two frame lengths the reference chunker emits (256 is also
     // BASELINE's framing) take the instantiation with the frame geometry folded in
-    if (uni.enabled) {
+    const bool lean_ok = diag == nullptr && prm.debug_stop == 0 && !prm.trial && prm.trial_res == nullptr;
+    if (uni.enabled && lean_ok) {
         if constexpr (W == 1 && SPL == 5) {
             if (uni.n == 256) return launch_class2<1, 5, false, 256>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
             if (uni.n == 128) return launch_class2<1, 5, false, 128>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);

@@ -881,16 +881,23 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
         zeros += (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
         if (dense) Xs[k] = make_float2(0.0f, 0.0f);  // the dense ladder's admitted spectrum
     };
-    // (every twiddle load of a thread is issued before the first one is used: a dependent global load per bin
-    // otherwise, with only two workgroups on the CU to hide it)
+    // A thread's row is fixed (w = tid + u PT, PT a multiple of FB): row, partner row and the bin of column 0 are
+    // computed once; every twiddle load of a thread is issued before the first one is used (a dependent global
+    // load per bin otherwise, with only two workgroups on the CU to hide it).
     constexpr uint32_t PU2 = (F4_MAX * FB + PT - 1) / PT;
+    const uint32_t r = threadIdx.x & (FB - 1), kc0 = threadIdx.x >> 4;
+    const bool live = r < nrow;
+    const uint32_t k1 = live ? row_of(r) : 0u;
+    const float2 *Rrow = R + r * ld;
+    // partner row and the column map k2 -> partner column (row 0: M2 - k2 with 0 -> 0; otherwise M2 - 1 - k2)
+    const bool row0 = blockIdx.x == 0 && r == 0;
+    const float2 *Rpart = R + ((blockIdx.x == 0) ? r : (nrow - 1 - r)) * ld;
     float2 twk[PU2];
 #pragma unroll
     for (uint32_t u = 0; u < PU2; ++u) {
-        const uint32_t w = threadIdx.x + u * PT;
-        const uint32_t r = w & (FB - 1), k2 = w >> 4;
+        const uint32_t k2 = kc0 + u * (PT / FB);
         twk[u] = make_float2(1.0f, 0.0f);
-        if (w < M2 * FB && r < nrow && f.half) twk[u] = tw[row_of(r) + M1 * k2];
+        if (live && k2 < M2 && f.half) twk[u] = tw[k1 + M1 * k2];
     }
     auto untangle = [&](float2 zk, float2 zm, float2 wk) -> float2 {  // see fft_untangle (atsc_kernels.hip)
         const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
@@ -900,20 +907,16 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
     };
 #pragma unroll
     for (uint32_t u = 0; u < PU2; ++u) {
-        const uint32_t w = threadIdx.x + u * PT;
-        const uint32_t r = w & (FB - 1), k2 = w >> 4;
-        if (w >= M2 * FB || r >= nrow) continue;
-        const uint32_t k1 = row_of(r), k = k1 + M1 * k2;
-        const float2 zk = R[r * ld + k2];
+        const uint32_t k2 = kc0 + u * (PT / FB);
+        if (!live || k2 >= M2) continue;
+        const uint32_t k = k1 + M1 * k2;
+        const float2 zk = Rrow[k2];
         if (!f.half) {  // complex transform of the real signal: bins 0 .. L / 2 are kept
             if (k < f.bins) finish(k, zk);
             else spec[k] = zk;
             continue;
         }
-        float2 zm;
-        if (blockIdx.x == 0 && r == 0) zm = R[(k2 == 0) ? 0 : (M2 - k2)];           // row 0: columns k2 <-> M2 - k2
-        else if (blockIdx.x == 0) zm = R[ld + (M2 - 1 - k2)];                        // the middle row mirrors itself
-        else zm = R[(nrow - 1 - r) * ld + (M2 - 1 - k2)];
+        const float2 zm = Rpart[row0 ? (k2 == 0 ? 0u : M2 - k2) : (M2 - 1 - k2)];
         finish(k, untangle(zk, zm, twk[u]));
         if (k == 0) finish(M, untangle(zk, zk, tw[M]));  // bin M: Z[0] with Z[0]
     }

@@ -740,6 +740,7 @@ def test_fixed_length_instantiation_matches_generic(ctx, A, monkeypatch, flen):
     import torch
 
     dev = torch.device("cuda", 0)
+    ctx.enable_diag(False)  # (a diagnostics record would route the uniform batch to the table-driven kernels too)
     nf = (1 << 20) // flen
     x = H.synth_series(11, nf * flen, block=8192)
     off = H.frame_offsets(len(x), flen)
