@@ -18,7 +18,15 @@
 
 namespace atsc {
 
-constexpr int LW = 16;          // wavefronts per workgroup
+// ATSC_DEBUG_STOP=-1: workgroup 0 prints the constant 100 MHz clock at the phase boundaries of k_compress_large
+// (tools/large_stamp_probe.py turns the lines into a phase table); everything runs as usual otherwise
+#define LT_STAMP(name)                                                                                   \
+    do {                                                                                                 \
+        if (prm.debug_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0)                                 \
+            printf("LTSTAMP part%d %s %llu\n", PART, name, (unsigned long long)wall_clock64());           \
+    } while (0)
+
+constexpr int LW = 16;          // wavefronts per workgroup (8 were tried: no register spills, but 25 % slower)
 constexpr int LT = 64 * LW;     // threads
 
 DEVI float2 cmulc(float2 v, float2 w)  // v * (w.x - i w.y)
@@ -1207,6 +1215,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         i = i < 0 ? 0 : (i >= (int32_t)n ? (int32_t)n - 1 : i);
         return xs[i];
     };
+    LT_STAMP("start");
 
     // ---- stats --------------------------------------------------------------------------------
     double smin, smax;
@@ -1366,6 +1375,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     };
 
     if (prm.debug_stop == 1) return;
+    LT_STAMP("stats done");
     // ---- RLE (rle.rs:142-189): bound first; exact right away when there are few runs ----
     uint32_t rle_size = 0xFFFFFFFFu, rle_R = 0, rle_D = 0, rle_ib = 0, rle_lb = 0xFFFFFFFFu;
     bool rle_sorted = false, rle_pending = false;
@@ -1488,6 +1498,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
 
     if (prm.debug_stop == 2) return;
+    LT_STAMP("rle done");
     // =========================================================================================
     // Polynomial candidate (polynomial.rs:209-277); forced Idw shares the ladder and swaps the
     // interpolation (polynomial.rs:375-393)
@@ -1704,6 +1715,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     }
 
 
+    LT_STAMP("poly first trip done");
     // =========================================================================================
     // FFT candidate (fft.rs:288-362)
     // =========================================================================================
@@ -1932,6 +1944,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
             uint32_t nkeys = PART == 2 ? fst->nkeys
                              : fft_hopeless ? 0u : build_order(min(kcap_total, max(2048u, P.mf + P.dk1)));
             if (prm.debug_stop == 5) return;
+            LT_STAMP("order built");
 
             // ---- ladder ----
             const bool wraps = bins > 65536;
@@ -1992,6 +2005,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 }
                 used = K;
                 if (!prm.bounded) { cur = 0.0; break; }
+                LT_STAMP("bins admitted");
                 }
                 double s = 0.0;
                 if (sparse && resume) {
@@ -2004,6 +2018,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     if (PART == 1 && fft_trips == 1) {
                         // the cut: bucket the list, leave the bounds and the state, the tiles run elsewhere
                         sparse_bucket(P, K, sel_entry, (SpEnt *)work, tw, (unsigned char *)keys, wsum);
+                        LT_STAMP("bucketed");
                         const SpLds sl = sp_lds(P, (unsigned char *)keys);
                         uint32_t *gb = (uint32_t *)((unsigned char *)Cb + TRIP_BOUNDS_OFF);
                         for (uint32_t e = tid; e < P.sp_mf; e += T) {
@@ -2105,6 +2120,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         dg.fft_err = fft_err;
     }
 
+    LT_STAMP("fft ladder done");
     if (prm.debug_stop == 6 || prm.debug_stop >= 16) return;
     // the polynomial ladder continues where its first trip stopped (see above the FFT block)
     if (run_poly && poly_active) {
@@ -2112,6 +2128,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         poly_finish();
     }
 
+    LT_STAMP("poly ladder done");
     if (prm.debug_stop == 7) return;
     // ---- RLE with many runs: exact size (hash of run values) only if its bound can still win ----
     if (run_rle && rle_pending) {
@@ -2261,6 +2278,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
         res[fid].chosen = (uint32_t)chosen;
         if (diag) diag[fid] = dg;
     }
+    LT_STAMP("emitted");
 }
 
 // One tile (SPB output columns) of the first FFT trip of one frame whose k_compress_large<1> stopped at the cut:
@@ -2336,7 +2354,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     kp.prefft = (pre && pre->tiles1) ? 1u : 0u;
     // Few large frames: each has a CU to itself and most CUs idle, so the tiles of the first FFT trip run as
     // a (tile, frame) grid between the two parts of the per-frame kernel.
-    const bool split = kp.prefft && kp.sparse_inv && kp.bounded && kp.debug_stop == 0 && !kp.trial && pre->sp_tiles &&
+    const bool split = kp.prefft && kp.sparse_inv && kp.bounded && kp.debug_stop <= 0 && !kp.trial && pre->sp_tiles &&
                        count <= LARGE_SPLIT_MAX;
     const uint32_t lds_tiles = SP_LDS_BYTES + 512;
     kp.prestats = (split && pre->chunks_n) ? 1u : 0u;
