@@ -179,5 +179,5 @@ def assert_summary(summary, nf, what=""):
         len(summary["fail"]), summary["fail"][:8])
     assert not summary["fail"], msg
     assert summary["boundary"] <= max(1, int(BOUNDARY_FRAC * nf)), msg
-    assert summary.get("tie", 0) <= max(1, int(TIE_FRAC * nf)), msg
+    assert summary.get("tie", 0) <= max(2, int(TIE_FRAC * nf)), msg
     return msg

@@ -34,8 +34,8 @@ for seed in seeds:
     for k in ("exact", "tol", "tie", "boundary"):
         tot[k] += s[k]
     tot["frames"] += len(offs) - 1
-    line = "seed %d e=%d comp=%d uniform=%d exact=%d tol=%d boundary=%d fail=%d" % (
-        seed, e, comp, uniform, s["exact"], s["tol"], s["boundary"], len(s["fail"]))
+    line = "seed %d e=%d comp=%d uniform=%d exact=%d tol=%d tie=%d boundary=%d fail=%d" % (
+        seed, e, comp, uniform, s["exact"], s["tol"], s["tie"], s["boundary"], len(s["fail"]))
     print(line, flush=True)
     for f in s["fail"][:5]:
         print("   FAIL frame %d n=%d: %s" % (f[0], int(off[f[0] + 1] - off[f[0]]), f[1]), flush=True)
