@@ -515,6 +515,21 @@ DEVI void hp_rebuild(uint64_t *h, uint32_t len)
         hp_sift_down_range(h, n, len);
     }
 }
+// The same rebuild by `nthreads` threads of a workgroup (all of them call it): BinaryHeap::rebuild sifts nodes
+// len / 2 - 1 ... 0 down one after the other, i.e. every node of a level after all nodes of the levels below it, and
+// the sift of a node touches its own subtree only -- the nodes of one level are independent, level by level.
+DEVI void hp_rebuild_parallel(uint64_t *h, uint32_t len, uint32_t tid, uint32_t nthreads)
+{
+    if (len < 2) return;
+    const uint32_t last_internal = len / 2 - 1;
+    int level = 31 - __clz((int)(last_internal + 1));  // level of the last internal node (root = level 0)
+    for (; level >= 0; --level) {
+        const uint32_t first = (1u << level) - 1u;
+        const uint32_t last = min(last_internal, (2u << level) - 2u);
+        for (uint32_t node = first + tid; node <= last; node += nthreads) hp_sift_down_range(h, node, len);
+        __syncthreads();
+    }
+}
 // BinaryHeap::pop; the popped entry is also left at h[len - 1] (the slot the heap gives up), so K pops of
 // a heap of `len` entries leave the pop sequence at h[len - 1], h[len - 2], ...
 DEVI uint64_t hp_pop(uint64_t *h, uint32_t &len)

@@ -907,7 +907,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             float bre[KPL], bim[KPL];  // W == 1: the lane's bins, so an admitted bin is one v_readlane away
             uint64_t *keys = (uint64_t *)(spec == A ? B : A);
             bool heap_order = false;  // bit-equal norms met: the admission order is replayed from the reference's heap
-            uint32_t hlen = 0;        // W == 1: entries left in the heap (keys[])
+            uint32_t hlen = 0;        // entries left in the heap (keys[]) once heap_order is set
+            uint32_t sorted_n = 0;    // W > 1: keys[0 .. sorted_n) hold the (norm desc, position asc) order
             uint32_t nz = 0;
             if (W == 1) {
 #pragma unroll
@@ -992,50 +993,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 uint32_t p2 = 1;
                 while (p2 < nk) p2 <<= 1;
                 block_sort<W, true>(keys, nullptr, nk, p2);
-                // Bit-equal norms among the bins the ladder can admit (or at the cut behind them): the
-                // reference's order is the BinaryHeap's, not (norm, position) -- replay the heap (hp_*,
-                // atsc_device.h).  Rare: two of <= kcap f32 norms have to collide.
-                uint32_t tied = 0;  // (matches of the cut norm) << 16 | adjacent equal pairs seen by this thread
-                for (uint32_t i = tid; i + 1 < nk; i += T) {  // (zero norms, key half 0xFFFFFFFF, are never admitted)
-                    const uint32_t hi = (uint32_t)(keys[i] >> 32);
-                    tied += (hi == (uint32_t)(keys[i + 1] >> 32) && hi != 0xFFFFFFFFu) ? 1u : 0u;
-                }
-                if (nk < bins && nk > 0 && (uint32_t)(keys[nk - 1] >> 32) != 0xFFFFFFFFu) {  // a bin left out by the select may tie with the last one kept
-                    const uint32_t last = (uint32_t)(keys[nk - 1] >> 32);
-                    for (uint32_t k = tid; k < bins; k += T) {
-                        const float2 z = spec[k];
-                        const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-                        // (the kept copy of the last key itself is one match; a second one is a tie)
-                        tied += ((~__float_as_uint(nrm)) == last) ? 0x10000u : 0u;
-                    }
-                }
-                tied = block_sum_u32<W>(tied, red, parity);
-                // every bin whose norm equals the cut norm sorts in front of the cut or right behind it: more
-                // matches over all bins than inside the kept list means the tie group straddles the cut
-                if ((tied & 0xffffu) != 0) heap_order = true;
-                if (nk < bins && nk > 0 && (uint32_t)(keys[nk - 1] >> 32) != 0xFFFFFFFFu) {
-                    uint32_t inside = 0;
-                    const uint32_t last = (uint32_t)(keys[nk - 1] >> 32);
-                    for (uint32_t i = tid; i < nk; i += T) inside += ((uint32_t)(keys[i] >> 32) == last) ? 1u : 0u;
-                    inside = block_sum_u32<W>(inside, red, parity);
-                    if ((tied >> 16) > inside) heap_order = true;
-                }
-                if (heap_order) {
-                    __syncthreads();
-                    for (uint32_t k = tid; k < bins; k += T) {
-                        const float2 z = spec[k];
-                        const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-                        keys[k] = ((uint64_t)__float_as_uint(nrm) << 32) | (uint64_t)k;
-                    }
-                    __syncthreads();
-                    if (tid < 64) {
-                        hp_rebuild(keys, bins);
-                        uint32_t hl = bins;
-                        const uint32_t want = min(kcap, Z);
-                        for (uint32_t i = 0; i < want; ++i) (void)hp_pop(keys, hl);  // pop i lands at keys[bins - 1 - i]
-                    }
-                    __syncthreads();
-                }
+                sorted_n = nk;
             }
 
             if (!LEAN && prm.debug_stop == 5) return;
@@ -1059,6 +1017,53 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 const uint32_t K = min(mf + jump, Z);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
+                if (W > 1 && !heap_order) {
+                    // Bit-equal norms among the bins this trip admits, or between the last of them and the next
+                    // one in line: the reference's order there is the BinaryHeap's, not (norm, position).  The
+                    // pairs up to (used - 1, used) were looked at by the trips before.  Rare -- two of the K
+                    // largest f32 norms have to collide -- and then the frame replays the heap (hp_*,
+                    // atsc_device.h): rebuilt level by level by the whole workgroup, popped by one wavefront,
+                    // pop i left at keys[bins - 1 - i].  The bins admitted so far had distinct norms, i.e. they
+                    // are the heap's first pops.
+                    uint32_t tied = 0;
+                    for (uint32_t i = used + tid; i < K && i + 1 < sorted_n; i += T) {
+                        const uint32_t hi = (uint32_t)(keys[i] >> 32);  // (zero norms, 0xFFFFFFFF, are never admitted)
+                        tied |= (hi == (uint32_t)(keys[i + 1] >> 32) && hi != 0xFFFFFFFFu) ? 1u : 0u;
+                    }
+                    if (K == sorted_n && sorted_n < bins && K > used) {
+                        // the ladder takes the last key the select kept: a bin it left out may hold the same norm
+                        const uint32_t hi = (uint32_t)(keys[sorted_n - 1] >> 32), lastpos = (uint32_t)(keys[sorted_n - 1] & 0xffffffffu);
+                        if (hi != 0xFFFFFFFFu)
+                            for (uint32_t k = tid; k < bins; k += T) {
+                                const float2 zz = spec[k];
+                                const float nrm = (float)sqrt((double)zz.x * (double)zz.x + (double)zz.y * (double)zz.y);
+                                tied |= ((~__float_as_uint(nrm)) == hi && k != lastpos) ? 1u : 0u;
+                            }
+                    }
+                    tied = block_sum_u32<W>(tied ? 1u : 0u, red, parity);
+                    if (!LEAN && prm.debug_stop == -2) tied = 0;  // A/B aid: (norm, position) order throughout
+                    if (tied) {
+                        __syncthreads();
+                        for (uint32_t k = tid; k < bins; k += T) {
+                            const float2 zz = spec[k];
+                            const float nrm = (float)sqrt((double)zz.x * (double)zz.x + (double)zz.y * (double)zz.y);
+                            keys[k] = ((uint64_t)__float_as_uint(nrm) << 32) | (uint64_t)k;
+                        }
+                        __syncthreads();
+                        hp_rebuild_parallel(keys, bins, tid, (uint32_t)T);
+                        hlen = bins;
+                        if (tid < 64)
+                            for (uint32_t i = 0; i < used; ++i) (void)hp_pop(keys, hlen);
+                        hlen = bins - used;
+                        heap_order = true;
+                    }
+                }
+                if (W > 1 && heap_order) {
+                    if (tid < 64)
+                        for (uint32_t i = used; i < K; ++i) (void)hp_pop(keys, hlen);
+                    hlen = bins - K;
+                    __syncthreads();
+                }
                 for (; used < K; ++used) {
                     uint32_t pos;
                     float2 z;
@@ -1091,7 +1096,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                                     }
                                 }
                                 __syncthreads();
-                                hp_rebuild(keys, bins);
+                                hp_rebuild_parallel(keys, bins, tid, 64u);
                                 hlen = bins;
                                 for (uint32_t i = 0; i < used; ++i) (void)hp_pop(keys, hlen);
                                 heap_order = true;
@@ -1723,8 +1728,8 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         if constexpr (W == 4 && SPL == 5) {
             if (uni.n == 1024) return launch_class2<4, 5, false, 1024>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
         }
-        if constexpr (W == 4 && SPL == 9) {
-            if (uni.n == 2048) return launch_class2<4, 9, false, 2048>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+        if constexpr (W == 8 && SPL == 5) {
+            if (uni.n == 2048) return launch_class2<8, 5, false, 2048>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
         }
         if constexpr (W == 16 && SPL == 5) {
             if (uni.n == 4096) return launch_class2<16, 5, false, 4096>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
@@ -1744,7 +1749,10 @@ hipError_t launch_compress_class(int cls, uint32_t count, uint32_t lds, const do
     case 1: return launch_class<1, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     case 2: return launch_class<1, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     case 3: return launch_class<4, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
-    case 4: return launch_class<4, 9>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
+    // (class 4, L <= 2304, ran as <4, 9> in round 1: 72 KB of LDS per frame leave two workgroups on a CU, and two
+    // workgroups of 4 wavefronts are 2 waves per SIMD; 8 wavefronts with 5 samples per lane double that: 2048-sample
+    // frames 33 -> 36 Gsamples/s.  The same step for class 3 -- <8, 3> instead of <4, 5> -- halves its rate.)
+    case 4: return launch_class<8, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     case 5: return launch_class<16, 5>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     default: return hipErrorInvalidValue;
     }
