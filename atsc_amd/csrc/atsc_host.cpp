@@ -30,7 +30,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
                                  unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
-                                 const LargePre *pre = nullptr);
+                                 const LargePre *pre = nullptr, hipStream_t s_frames = nullptr,
+                                 hipEvent_t ev_grids = nullptr, int *used_frames_stream = nullptr);
 uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
@@ -75,6 +76,7 @@ struct atsc_ctx {
     std::map<void *, size_t> pool_live;
     size_t pool_held = 0;
     hipStream_t pack_stream = nullptr;  // created by the first pipelined call
+    hipStream_t frame_stream = nullptr; // pipelined calls: the large tier's per-frame kernels (launch_compress_large)
     bool adaptive_order = true;         // pipelined calls start a class's costliest frames first
     int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
     // optional timing of the dominant k_compress launch (HIP events on the launch stream)
@@ -148,6 +150,8 @@ struct atsc_plan {
     mutable Scratch alt;
     mutable int turn = 0;
     mutable hipEvent_t ev_codec[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_grids[2] = {nullptr, nullptr}, ev_frames[2] = {nullptr, nullptr};  // large tier on two streams
+    mutable unsigned char *d_ws_alt = nullptr;  // second workspace set of the large tier (pipelined calls)
     mutable bool pack_pending[2] = {false, false};
     uint64_t slots_bytes = 0;
     // scheduling hint of the pipelined path: clocks per frame in the last batch, and the launch
@@ -525,6 +529,7 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
+    if (ctx->frame_stream) (void)hipStreamDestroy(ctx->frame_stream);
     for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
     // blocks still held by plans that outlive their context (a contract violation) are left alone: their
     // owners would otherwise free them a second time
@@ -605,6 +610,7 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     pool_free(p->ctx, p->d_local);
     pool_free(p->ctx, p->d_blocksum);
     pool_free(p->ctx, p->d_ws);
+    pool_free(p->ctx, p->d_ws_alt);
     pool_free(p->ctx, p->alt.d_res);
     pool_free(p->ctx, p->alt.d_slots);
     pool_free(p->ctx, p->alt.d_local);
@@ -617,6 +623,8 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     for (int k = 0; k < 2; ++k) {
         if (p->ev_codec[k]) (void)hipEventDestroy(p->ev_codec[k]);
         if (p->ev_pack[k]) (void)hipEventDestroy(p->ev_pack[k]);
+        if (p->ev_grids[k]) (void)hipEventDestroy(p->ev_grids[k]);
+        if (p->ev_frames[k]) (void)hipEventDestroy(p->ev_frames[k]);
     }
     delete p;
 }
@@ -911,6 +919,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             }
     }
     hipEvent_t codec_done = nullptr;  // already attached to the last codec dispatch, if any
+    hipEvent_t frames_event = nullptr;  // the large tier's per-frame kernels ran on the context's frame stream
     const bool adapt = pipelined && ctx->adaptive_order;
     bool want_order = false;  // set once the main launches (which record the costs) are enqueued
     const uint32_t *ids_main = (adapt && plan->adapt_valid[k]) ? plan->d_ids_adapt[k] : plan->d_ids;
@@ -921,6 +930,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
                 codec_done = plan->ev_codec[k];
             }
             HIPCHK(ctx, hipStreamWaitEvent(ps, codec_done, 0));
+            if (frames_event) HIPCHK(ctx, hipStreamWaitEvent(ps, frames_event, 0));
         }
         hipError_t e = launch_pack(plan->d_frames, S.d_res, plan->n_frames, S.d_local, S.d_blocksum,
                                    S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err,
@@ -1050,10 +1060,36 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             // the pre-pass transforms every large frame; a trial launch or a forced codec other than
             // FFT / Auto would not use its results
             const bool pre = plan->large_pre.tiles1 && (compressor == ATSC_AUTO || compressor == ATSC_FFT);
+            unsigned char *ws = plan->d_ws;
+            hipStream_t sf = nullptr;
+            hipEvent_t evg = nullptr;
+            int on_frames = 0;
+            if (pipelined && pre && plan->class_count[c] <= plan->ws_slots && !getenv("ATSC_LARGE_ONE_STREAM")) {
+                // two workspace sets and a stream for the per-frame kernels: they overlap the next batch's grids
+                if (!ctx->frame_stream) {
+                    // (highest priority: these few latency-bound workgroups should start the moment their grids are done,
+                    // not queue behind the next batch's grid workgroups)
+                    int least = 0, greatest = 0;
+                    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->frame_stream, hipStreamNonBlocking, greatest));
+                }
+                if (!plan->d_ws_alt) HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ws_alt, plan->ws_stride * plan->ws_slots));
+                for (int i = 0; i < 2; ++i) {
+                    if (!plan->ev_grids[i]) HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_grids[i], hipEventDisableTiming));
+                    if (!plan->ev_frames[i]) HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_frames[i], hipEventDisableTiming));
+                }
+                if (k) ws = plan->d_ws_alt;
+                sf = ctx->frame_stream;
+                evg = plan->ev_grids[k];
+            }
             e = launch_compress_large(plan->class_count[c], d_samples, plan->d_frames,
                                       plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
-                                      plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag, plan->d_ws,
-                                      plan->ws_stride, plan->ws_slots, s, pre ? &plan->large_pre : nullptr);
+                                      plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag, ws,
+                                      plan->ws_stride, plan->ws_slots, s, pre ? &plan->large_pre : nullptr, sf, evg, &on_frames);
+            if (e == hipSuccess && on_frames) {
+                HIPCHK(ctx, hipEventRecord(plan->ev_frames[k], ctx->frame_stream));
+                frames_event = plan->ev_frames[k];
+            }
         }
         else {
             UniArgs u = plan->class_uni[c];

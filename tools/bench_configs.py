@@ -30,6 +30,33 @@ def run_compress(x, off, comp, bounded, me, reps=5, level=0):
     return dt, total, body, {int(c): int(np.sum(chosen == c)) for c in np.unique(chosen)}
 
 
+def run_compress_pipelined(xs_list, off, comp, bounded, me, reps=12, level=0):
+    """Batch after batch through atsc_compress_plan_dev_pipelined: rotating resident batches, two output sets.
+    Returns (seconds per batch, bytes of the last batch, bytes equal to the plain call's?)."""
+    plan = ctx.plan(off)
+    d_xs = [torch.from_numpy(v).to(dev) for v in xs_list]
+    outs = [plan.alloc_outputs(torch, dev), plan.alloc_outputs(torch, dev)]
+    ref = plan.alloc_outputs(torch, dev)
+    for i in range(4):
+        plan.compress(d_xs[i % len(d_xs)], outs[i % 2], comp, bounded, me, level, st, pipelined=True)
+    plan.join(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        plan.compress(d_xs[i % len(d_xs)], outs[i % 2], comp, bounded, me, level, st, pipelined=True)
+    plan.join(st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    last = (reps - 1)
+    total = int(outs[last % 2]["rec_off"][-1].item())
+    got = outs[last % 2]["body"][:total].cpu().numpy().tobytes()
+    plan.compress(d_xs[last % len(d_xs)], ref, comp, bounded, me, level, st)
+    torch.cuda.synchronize()
+    rt = int(ref["rec_off"][-1].item())
+    same = rt == total and ref["body"][:rt].cpu().numpy().tobytes() == got
+    return dt, total, same
+
+
 def run_decompress(body, n_samples, reps=5):
     dp = atsc_amd.DPlan(ctx, body)
     d_body = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(dev)
@@ -67,6 +94,12 @@ dt, tot, body, cod = run_compress(x, off, atsc_amd.AUTO, True, me5, reps=3)
 report("configs[2] 10M auto e=5%% reference chunker framing (%d x 131072)" % len(sizes), n, dt, tot, cod)
 dtd = run_decompress(body, n, reps=3)
 report("configs[4]-like decompress of the above", n, dtd, tot, cod)
+# the same framing batch after batch (four different series rotating) through the pipelined entry point: the large
+# tier's per-frame kernels of batch i overlap the grids of batch i + 1
+xsl = [x] + [H.synth_series(s, n) for s in (1, 2, 3)]
+dtp, totp, same = run_compress_pipelined(xsl, off, atsc_amd.AUTO, True, me5)
+print(json.dumps({"config": "configs[2] chunker framing, pipelined entry point, 4 batches rotating", "samples": n,
+                  "ms": round(dtp * 1e3, 3), "Msamples_s": round(n / dtp / 1e6, 1), "bytes_equal_plain_call": same}), flush=True)
 # configs[2] F256 + decompress
 dt, tot, body, cod = run_compress(x, H.frame_offsets(n, 256), atsc_amd.AUTO, True, me5, reps=10)
 report("configs[2] 10M auto e=5% f256", n, dt, tot, cod)

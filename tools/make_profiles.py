@@ -1,0 +1,89 @@
+"""Turns the scratch output of one profiling call (gpurun_out/<tag>_*) into the committed summaries under profiles/:
+kernel stats, bench lines, the PMC summary with the VALU issue model, the large tier's per-kernel traffic.
+usage: python tools/make_profiles.py r02"""
+import collections, csv, glob, io, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def first(pattern):
+    fs = sorted(glob.glob(pattern))
+    return fs[0] if fs else None
+
+
+# 1. kernel stats of the headline bench
+f = first(os.path.join(G, tag + "_stats", "*", "*kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
+for name in ("bench", "stats_bench", "bench_share2"):
+    src = os.path.join(G, "%s_%s.json" % (tag, name))
+    if os.path.exists(src):
+        lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(P, "%s_%s.json" % (tag, name)), "w").write(lines[-1] + "\n")
+for name in ("other_configs", "config3_full_1gpu", "length_probe"):
+    src = os.path.join(G, "%s_%s.txt" % (tag, name))
+    if os.path.exists(src):
+        txt = "\n".join(l for l in open(src).read().splitlines() if "amdgpu.ids" not in l)
+        open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(txt + "\n")
+
+# 2. PMC summary + VALU issue model
+agg = collections.defaultdict(list)
+for f in glob.glob(os.path.join(G, tag + "_pmc", "pass*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "k_compress" in r["Kernel_Name"] and "256" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if agg:
+    c = {k: sum(v) / len(v) for k, v in agg.items()}
+    launches = len(next(iter(agg.values())))
+    f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
+    tr64 = c.get("SQ_INSTS_VALU_TRANS_F64", 0)
+    cvt = c.get("SQ_INSTS_VALU_CVT", 0)
+    valu = c.get("SQ_INSTS_VALU", 0)
+    other = valu - f64 - tr64 - cvt
+    cycles = other * 2 + f64 * 4 + tr64 * 16 + cvt * 4
+    floor_us = cycles / 1024.0 / 2400.0
+    frames = c.get("SQ_WAVES", 40960)
+    fetch = 2 * 1024 * c.get("FETCH_SIZE", 0)
+    write = 1024 * c.get("WRITE_SIZE", 0)
+    out = {
+        "note": "rocprofv3 --pmc passes (tools/pmc_collect.sh: one counter set per pass, --kernel-trace only) over "
+                "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end`; averages per "
+                "k_compress<1,5,false,256> launch (%d launches).  FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes "
+                "for gfx950 (128-B requests tallied at 64 B); FETCH / WRITE unit KiB; SQ_WAVE_CYCLES, SQ_WAIT_*, "
+                "SQ_ACTIVE_INST_* count quad-cycles." % launches,
+        "counters_per_launch": c,
+        "hbm_bytes_per_launch": {"read": fetch, "write": write, "total": fetch + write},
+        "per_frame": {"valu": valu / frames, "valu_f64_add_mul_fma": f64 / frames, "valu_f64_trans": tr64 / frames,
+                      "valu_cvt": cvt / frames, "salu": c.get("SQ_INSTS_SALU", 0) / frames, "lds": c.get("SQ_INSTS_LDS", 0) / frames,
+                      "smem": c.get("SQ_INSTS_SMEM", 0) / frames,
+                      "wave_cycles": 4 * c.get("SQ_WAVE_CYCLES", 0) / frames},
+        "wave_time_split": {k: c.get(k, 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1) for k in
+                            ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
+    }
+    json.dump(out, open(os.path.join(P, tag + "_pmc.json"), "w"), indent=1)
+    model = {
+        "issue_floor_us_per_launch": floor_us,
+        "source": "%s_pmc.json: (%.1f M other VALU x 2 + %.1f M f64 add/mul/fma x 4 + %.2f M f64 rcp/rsq x 16 + %.1f M "
+                  "conversions x 4) cycles / 1024 SIMDs / 2.4 GHz" % (tag, other / 1e6, f64 / 1e6, tr64 / 1e6, cvt / 1e6),
+        "valu_wave_instructions_per_launch": valu,
+    }
+    json.dump(model, open(os.path.join(P, "valu_model.json"), "w"), indent=1)
+    print("VALU floor %.1f us per launch; HBM %.1f MB" % (floor_us, (fetch + write) / 1e6))
+
+# 3. large tier: kernel stats and traffic per kernel
+for nf in (80, 256):
+    st = os.path.join(G, "%s_large%d" % (tag, nf))
+    f = first(os.path.join(st, "*", "*kernel_stats.csv"))
+    if not f:
+        continue
+    shutil.copy(f, os.path.join(P, "%s_large%d_kernel_stats.csv" % (tag, nf)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), st, st + "_fetch", st + "_write"],
+                       capture_output=True, text=True)
+    head = ("%d frames x 131072 samples (%.1f MB of samples; mixed classes, auto, e = 5 %%): per kernel, average duration, HBM "
+            "bytes read (FETCH_SIZE doubled, gfx950) and written per launch, from three rocprofv3 runs of tools/large_trace.py "
+            "(--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE)\n" % (nf, nf * 131072 * 8 / 1e6))
+    open(os.path.join(P, "%s_large%d_traffic.txt" % (tag, nf)), "w").write(head + r.stdout)
+    print(r.stdout)
