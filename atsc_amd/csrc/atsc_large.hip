@@ -854,8 +854,13 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
     uint32_t *nbits = (uint32_t *)(f.ws + lay.o_nb);
     float2 *Xs = (float2 *)(f.ws + lay.o_x);
     const float2 *tw = twpool + P->tw_off;
-    const uint32_t ld = M2 + 1;
-    float2 *T = (float2 *)smem, *U = T + FB * ld, *w2 = U + FB * ld;
+    // Tile layout: point n2 of row r at n2 * SI + r (the rows interleaved, SI = FB + 1).  With a row's points
+    // contiguous instead (k_large_pre2's layout) consecutive lanes are consecutive butterflies of one row, and a
+    // radix-4 stage writes its outputs 4 points apart: 8 dwords, four banks for 64 lanes.  Interleaved, consecutive
+    // lanes are consecutive rows -- consecutive banks in every stage -- and the odd stride keeps the transposing
+    // store of the contiguous rows off a single bank as well.
+    constexpr uint32_t SI = FB + 1;
+    float2 *T = (float2 *)smem, *U = T + SI * M2, *w2 = U + SI * M2;
     for (uint32_t e = threadIdx.x; e < M2; e += PT) w2[e] = tw[e * (M1 * f.sc)];
     const uint32_t mg_m2 = (uint32_t)(0x100000000ull / M2) + 1u;
     {
@@ -875,12 +880,12 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
             const uint32_t w = threadIdx.x + u * PT;
             if (w < nrow * M2) {
                 const uint32_t r = __umulhi(w, mg_m2), n2 = w - r * M2;
-                T[r * ld + n2] = v[u];
+                T[n2 * SI + r] = v[u];
             }
         }
     }
     __syncthreads();
-    const float2 *R = lds_fft<false>(T, U, w2, M2, nrow, 1, ld, PT);
+    const float2 *R = lds_fft<true>(T, U, w2, M2, nrow, SI, 1, PT);
     const bool dense = !(sparse_inv && P->sp_mf);
     uint32_t zeros = 0;
     auto finish = [&](uint32_t k, float2 z) {
@@ -896,10 +901,10 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
     const uint32_t r = threadIdx.x & (FB - 1), kc0 = threadIdx.x >> 4;
     const bool live = r < nrow;
     const uint32_t k1 = live ? row_of(r) : 0u;
-    const float2 *Rrow = R + r * ld;
+    const float2 *Rrow = R + r;   // point k2 of this thread's row: Rrow[k2 * SI]
     // partner row and the column map k2 -> partner column (row 0: M2 - k2 with 0 -> 0; otherwise M2 - 1 - k2)
     const bool row0 = blockIdx.x == 0 && r == 0;
-    const float2 *Rpart = R + ((blockIdx.x == 0) ? r : (nrow - 1 - r)) * ld;
+    const float2 *Rpart = R + ((blockIdx.x == 0) ? r : (nrow - 1 - r));
     float2 twk[PU2];
 #pragma unroll
     for (uint32_t u = 0; u < PU2; ++u) {
@@ -918,13 +923,13 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
         const uint32_t k2 = kc0 + u * (PT / FB);
         if (!live || k2 >= M2) continue;
         const uint32_t k = k1 + M1 * k2;
-        const float2 zk = Rrow[k2];
+        const float2 zk = Rrow[k2 * SI];
         if (!f.half) {  // complex transform of the real signal: bins 0 .. L / 2 are kept
             if (k < f.bins) finish(k, zk);
             else spec[k] = zk;
             continue;
         }
-        const float2 zm = Rpart[row0 ? (k2 == 0 ? 0u : M2 - k2) : (M2 - 1 - k2)];
+        const float2 zm = Rpart[(row0 ? (k2 == 0 ? 0u : M2 - k2) : (M2 - 1 - k2)) * SI];
         finish(k, untangle(zk, zm, twk[u]));
         if (k == 0) finish(M, untangle(zk, zk, tw[M]));  // bin M: Z[0] with Z[0]
     }
@@ -2376,7 +2381,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     uint32_t lds1 = 0, lds2 = 0;
     if (kp.prefft) {
         lds1 = (2 * FB * pre->m1_max + pre->m1_max) * (uint32_t)sizeof(float2);
-        lds2 = (2 * FB * (pre->m2_max + 1) + pre->m2_max) * (uint32_t)sizeof(float2);
+        lds2 = (2 * (FB + 1) * pre->m2_max + pre->m2_max) * (uint32_t)sizeof(float2);
         e = ensure_dyn_lds((const void *)k_large_pre1<DevFrame, false>, lds1);
         if (e != hipSuccess) return e;
         e = ensure_dyn_lds((const void *)k_large_pre23, lds2);
