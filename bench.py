@@ -201,6 +201,58 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
     return out
 
 
+def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
+    """The same batches in the reference CLI's own framing (OptimizerPlan::get_chunks_sizes, optimizer/mod.rs:78-98:
+    80 frames of 131072 samples), device resident: plain calls, and batch after batch through the pipelined entry
+    point.  Extra information next to `value` (which is the 256-sample framing BASELINE.json names)."""
+    n = d_xs[0].numel()
+    sizes = atsc_amd.chunk_sizes(n)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    plan = ctx.plan(off)
+    outs = [plan.alloc_outputs(torch, dev), plan.alloc_outputs(torch, dev)]
+    R = len(d_xs)
+    for i in range(2):
+        plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
+    torch.cuda.synchronize()
+    reps = 8
+    t0 = time.perf_counter()
+    for i in range(reps):
+        plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
+    torch.cuda.synchronize()
+    dt_plain = (time.perf_counter() - t0) / reps
+    total = int(outs[0]["rec_off"][-1].item())
+    body = outs[0]["body"][:total].cpu().numpy().tobytes()
+    for i in range(4):
+        plan.compress(d_xs[i % R], outs[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+    plan.join(stream)
+    torch.cuda.synchronize()
+    reps = 12
+    t0 = time.perf_counter()
+    for i in range(reps):
+        plan.compress(d_xs[i % R], outs[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+    plan.join(stream)
+    torch.cuda.synchronize()
+    dt_pipe = (time.perf_counter() - t0) / reps
+    dp = atsc_amd.DPlan(ctx, body)
+    d_body = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(dev)
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        dp.decompress(d_body, d_out, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dp.decompress(d_body, d_out, stream)
+    torch.cuda.synchronize()
+    dt_dec = (time.perf_counter() - t0) / 5
+    dp.close()
+    plan.close()
+    return {"frames": len(sizes), "frame_len": int(sizes[0]), "ratio": 8.0 * n / (total + 12),
+            "compress": {"value": n / dt_plain / 1e6, "unit": "Msamples/s", "ms": dt_plain * 1e3},
+            "compress_pipelined": {"value": n / dt_pipe / 1e6, "unit": "Msamples/s", "ms": dt_pipe * 1e3},
+            "decompress": {"value": n / dt_dec / 1e6, "unit": "Msamples/s", "ms": dt_dec * 1e3},
+            "note": "device resident; the reference chunker's framing of the same batches (the atsc CLI's framing)"}
+
+
 ROTATE = 4          # resident batches the timed loop cycles through (N = 1 workload)
 C3_SERIES = 4096    # configs[3]: 4096 series x 262144 samples = 2^30
 C3_PER = 262144
@@ -492,6 +544,7 @@ def main():
             except Exception:
                 pass
         if world == 1 and workload == "config2" and not args.no_end_to_end:
+            out["chunker_framing"] = chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream)
             out["end_to_end"] = end_to_end(ctx, atsc_amd, xs[0], off, me)
         if world == 1 and workload == "config2" and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(xs[0], off, me)

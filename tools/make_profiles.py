@@ -8,9 +8,9 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
 
-def first(pattern):
-    fs = sorted(glob.glob(pattern))
-    return fs[0] if fs else None
+def first(pattern):  # the newest match: gpurun merges every call's files into the same directories
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1] if fs else None
 
 
 # 1. kernel stats of the headline bench
@@ -31,7 +31,10 @@ for name in ("other_configs", "config3_full_1gpu", "length_probe"):
 
 # 2. PMC summary + VALU issue model
 agg = collections.defaultdict(list)
-for f in glob.glob(os.path.join(G, tag + "_pmc", "pass*", "*", "*counter_collection.csv")):
+for d in sorted(glob.glob(os.path.join(G, tag + "_pmc", "pass*"))):
+    f = first(os.path.join(d, "*", "*counter_collection.csv"))
+    if not f:
+        continue
     for r in csv.DictReader(open(f)):
         if "k_compress" in r["Kernel_Name"] and "256" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

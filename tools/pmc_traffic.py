@@ -1,17 +1,17 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE counter_collection CSVs) next
 to the kernel durations of a --kernel-trace --stats pass.  gfx950: FETCH_SIZE is doubled (128-B requests tallied at
 64 B, MI355X_MICROARCH.md); counter unit KiB.  usage: pmc_traffic.py <stats dir> <fetch dir> <write dir> [launches to skip]"""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 def counters(d, name):
     agg = collections.defaultdict(list)
-    for f in glob.glob(d + '/*/*counter_collection.csv'):
+    for f in sorted(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)[-1:]:  # the newest run only
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == name:
                 agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
     return agg
 def durations(d):
     out = {}
-    for f in glob.glob(d + '/*/*kernel_stats.csv'):
+    for f in sorted(glob.glob(d + '/*/*kernel_stats.csv'), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             out[r['Name'].split('(')[0]] = (int(r['Calls']), float(r['AverageNs']) / 1e3)
     return out
