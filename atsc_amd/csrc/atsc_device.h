@@ -201,12 +201,20 @@ DEVI double dpp_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// (quad_perm / row_ror give every lane a source: v_mov_b32_dpp without an `old` operand to initialise)
+template <int CTRL>
+DEVI double dpp_f64_full(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 DEVI double wave_sum_f64(double v)
 {
-    v += dpp_f64<0xb1, 0xf>(v);
-    v += dpp_f64<0x4e, 0xf>(v);
-    v += dpp_f64<0x124, 0xf>(v);
-    v += dpp_f64<0x128, 0xf>(v);
+    v += dpp_f64_full<0xb1>(v);
+    v += dpp_f64_full<0x4e>(v);
+    v += dpp_f64_full<0x124>(v);
+    v += dpp_f64_full<0x128>(v);
     v += dpp_f64<0x142, 0xa>(v);
     v += dpp_f64<0x143, 0xc>(v);
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
