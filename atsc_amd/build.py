@@ -5,7 +5,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libatsc_hip.so")
+# ATSC_BUILD_VARIANT=<name> ATSC_BUILD_DEFS="-DX ..." builds a side-by-side dev library libatsc_hip_<name>.so
+# (objects under build_<name>/), loaded by atsc_amd.capi when ATSC_LIB_VARIANT=<name> (tools/stamp_probe.py)
+VARIANT = os.environ.get("ATSC_BUILD_VARIANT", "")
+LIB = os.path.join(HERE, "libatsc_hip%s.so" % ("_" + VARIANT if VARIANT else ""))
 SOURCES = ["atsc_kernels.hip", "atsc_large.hip", "atsc_decode.hip", "atsc_host.cpp", "atsc_stream.cpp",
            "atsc_vsri.cpp"]
 CLI = os.path.join(HERE, "bin", "atsc")
@@ -25,15 +28,17 @@ def _hipcc():
 
 
 def stale():
+    if VARIANT:
+        return True
     if not os.path.exists(LIB) or not os.path.exists(CLI) or not os.path.exists(CLI2):
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(CLI), os.path.getmtime(CLI2))
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS + [CLI_SRC, CLI2_SRC])
 
 
-OBJDIR = os.path.join(HERE, "build")
+OBJDIR = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
 HEADERS = ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
-CFLAGS = [f for f in FLAGS if f != "-shared"]
+CFLAGS = [f for f in FLAGS if f != "-shared"] + os.environ.get("ATSC_BUILD_DEFS", "").split()
 
 
 def _obj_stale(src, obj):
@@ -70,6 +75,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    if VARIANT:
+        return LIB
     # the `atsc` command line front end (plain C++ over the C ABI)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     cli = [_hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(CSRC, CLI_SRC), "-L" + HERE, "-latsc_hip",

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libatsc_hip.so")
+_VARIANT = os.environ.get("ATSC_LIB_VARIANT", "")  # dev builds of atsc_amd.build (instrumented kernels), never the default
+LIB_PATH = os.path.join(_HERE, "libatsc_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
 NOOP, FFT, IDW, CONSTANT, POLYNOMIAL, AUTO, RLE = 0, 1, 2, 3, 4, 5, 6
 COMPRESSOR_NAMES = {0: "noop", 1: "fft", 2: "idw", 3: "constant", 4: "polynomial", 5: "auto", 6: "rle"}

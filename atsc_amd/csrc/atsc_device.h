@@ -222,6 +222,22 @@ DEVI double wave_sum_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// for (j = tid; j < n; j += T) f(j) -- with a compile-time length FN (0: not fixed) the trips are unrolled, so
+// that the loads of all trips issue together instead of one LDS round trip per (divergent) loop trip.
+template <int FN, int T, typename F>
+DEVI void for_strided(uint32_t tid, uint32_t n, F &&f)
+{
+    if constexpr (FN != 0) {
+#pragma unroll
+        for (int m = 0; m < (FN + T - 1) / T; ++m) {
+            const uint32_t j = tid + (uint32_t)(m * T);
+            if (FN % T == 0 || j < (uint32_t)FN) f(j);
+        }
+    } else {
+        for (uint32_t j = tid; j < n; j += T) f(j);
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // workgroup collectives (W wavefronts).  All return the same bits in every thread.
 // --------------------------------------------------------------------------------------------
@@ -254,8 +270,10 @@ DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
     return s;
 }
 
-// wavefront min / max of f64 by compare-select (no v_min_f64: NaN and signed-zero behaviour must be
-// the plain `<` / `>` of the reference's scan).  Lanes without a DPP source read themselves.
+// wavefront min / max of f64.  The lane values come out of the reference's scan (strict compares from data[0]):
+// either none of them is a NaN or all of them are (data[0] is one), so fmin / fmax return what a compare-select
+// chain would; which zero of +0.0 / -0.0 survives is open either way and the caller looks the first one up.
+// Lanes without a DPP source read themselves.
 template <int CTRL, int ROWMASK>
 DEVI double dpp_f64_self(double v)
 {
@@ -266,17 +284,17 @@ DEVI double dpp_f64_self(double v)
 template <bool IsMin>
 DEVI double wave_minmax_f64(double v)
 {
-#define ATSC_MM_STEP(CTRL, RM)                                   \
+#define ATSC_MM_STEP(O)                                          \
     {                                                            \
-        const double o = dpp_f64_self<CTRL, RM>(v);              \
-        v = (IsMin ? (o < v) : (o > v)) ? o : v;                 \
+        const double o = O;                                      \
+        v = IsMin ? fmin(o, v) : fmax(o, v);                     \
     }
-    ATSC_MM_STEP(0xb1, 0xf)
-    ATSC_MM_STEP(0x4e, 0xf)
-    ATSC_MM_STEP(0x124, 0xf)
-    ATSC_MM_STEP(0x128, 0xf)
-    ATSC_MM_STEP(0x142, 0xa)
-    ATSC_MM_STEP(0x143, 0xc)
+    ATSC_MM_STEP(dpp_f64_full<0xb1>(v))
+    ATSC_MM_STEP(dpp_f64_full<0x4e>(v))
+    ATSC_MM_STEP(dpp_f64_full<0x124>(v))
+    ATSC_MM_STEP(dpp_f64_full<0x128>(v))
+    ATSC_MM_STEP((dpp_f64_self<0x142, 0xa>(v)))
+    ATSC_MM_STEP((dpp_f64_self<0x143, 0xc>(v)))
 #undef ATSC_MM_STEP
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);

@@ -254,6 +254,17 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // --------------------------------------------------------------------------------------------
 // the frame kernel
 // --------------------------------------------------------------------------------------------
+#ifdef ATSC_STAMPS
+// Dev build only (-DATSC_STAMPS, tools/stamp_probe.py): shader-clock cycles per phase of the fixed-length
+// one-wavefront kernel.  A frame sums its phases in LDS (128 static bytes: 22 instead of 23 frames per CU) and
+// adds them to one of 64 global rows when it ends.
+__device__ unsigned long long g_phase_cyc[64 * 16];
+__device__ unsigned long long g_frame_span[65536 * 2];  // wall clock (100 MHz) at a frame's start and end, by launch slot
+#define PH(i) do { if (W == 1 && FN != 0) { const long long now_ = clock64(); \
+    if (tid == 0) atomicAdd(&ph_acc[i], (unsigned long long)(now_ - ph_t)); ph_t = clock64(); } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
 // one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs).
 // FN != 0: every frame of the launch has FN samples (FN >= 128, even transform length) and the frame
 // geometry is folded at compile time; FN == 0 reads it from the per-length table.
@@ -270,6 +281,13 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     uint32_t fid;
     DevFrame fr;
     const long long t_start = prm.cost ? clock64() : 0;
+#ifdef ATSC_STAMPS
+    __shared__ unsigned long long ph_acc[16];
+    if (tid < 16) ph_acc[tid] = 0;
+    __syncthreads();
+    long long ph_t = clock64();
+    if (W == 1 && FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[2 * blockIdx.x] = wall_clock64();
+#endif
     if (uni.enabled) {
         const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0 : blockIdx.x;
         fid = uni.fid0 + r;
@@ -285,7 +303,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     constexpr bool FIX = FN != 0;
     // The fixed-length instantiations are the production path: no diagnostics record, no phase stops, no
     // sample-level trial (launch_class routes those calls to the table-driven instantiation).  Their
-    // bookkeeping would otherwise sit in scalar registers for the whole kernel.
+    // bookkeeping would otherwise sit in scalar registers for the whole kernel.  They also only serve the auto
+    // selector with an error bound >= 0 (`atsc -e`, BASELINE's configurations): mode, bounded and prune fold.
     constexpr bool LEAN = FIX;
     constexpr uint32_t cL = FIX ? cx_next_size(FIX ? FN : 1) : 0, cmf = (3 >= FN / 100) ? 3 : FN / 100;
     static_assert(!FIX || (FN >= 128 && cL <= 64 * W * SPL), "fixed-length instantiation");
@@ -317,7 +336,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     int parity = 0;
 
     uint8_t *out = slots + fr.slot_off;
-    int mode = prm.mode;
+    int mode = LEAN ? (int)ATSC_AUTO : prm.mode;
+    const bool bounded = LEAN ? true : (prm.bounded != 0);
 
     // ---- load samples (the twiddles follow when the FFT candidate starts: until then and after
     // its ladder their region hosts `aux` and the RLE group table) ----------------------------
@@ -326,13 +346,14 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
             const double2 *src2 = (const double2 *)src;
             double2 *xs2 = (double2 *)xs;
-            for (uint32_t j = tid; j < (n >> 1); j += T) xs2[j] = src2[j];
+            for_strided<FN / 2, T>(tid, n >> 1, [&](uint32_t j) { xs2[j] = src2[j]; });
         } else {
             for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
         }
     }
     __syncthreads();
 
+    PH(0);
     // ---- stats (optimizer/utils.rs:39-89): min / max are the FIRST occurrence of the extreme
     // value (strict compares), so +0.0 / -0.0 resolve as the sequential scan does ---------------
     double smin, smax;
@@ -341,12 +362,12 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         const double x0 = xs[0];
         double mn = x0, mx = x0;
         uint32_t fr_any = 0;
-        for (uint32_t j = tid; j < n; j += T) {
+        for_strided<FN, T>(tid, n, [&](uint32_t j) {
             const double v = xs[j];
             fr_any |= frac_nonzero(v) ? 1u : 0u;
             if (v > mx) mx = v;
             if (v < mn) mn = v;
-        }
+        });
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
         fr_any = block_or_u32<W>(fr_any, red, parity);
@@ -357,11 +378,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         smax = mx;
         if (mn == 0.0 || mx == 0.0) {
             uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
-            for (uint32_t j = tid; j < n; j += T) {
+            for_strided<FN, T>(tid, n, [&](uint32_t j) {
                 const double v = xs[j];
                 if (v == mn) mni = min(mni, j);
                 if (v == mx) mxi = min(mxi, j);
-            }
+            });
             mni = block_min_u32<W>(mni, red, parity);
             mxi = block_min_u32<W>(mxi, red, parity);
             if (mni < n) smin = xs[mni];
@@ -374,6 +395,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         bitdepth = fr_any ? 0u : bitdepth_of(maxi, mini);
     }
 
+    PH(1);
     if (!LEAN && prm.debug_stop == 1) return;
     atsc_frame_diag dg;
     dg.fft_size = dg.poly_size = dg.rle_size = 0xFFFFFFFFu;
@@ -440,7 +462,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     const bool idw = IDW && (mode == ATSC_IDW);
     const double me = prm.max_err;
     // RLE reports error 0.0: it passes, and bounds the others, exactly when 0.0 <= max_error
-    const bool prune = (mode == ATSC_AUTO) && (0.0 <= me);
+    const bool prune = LEAN ? true : (mode == ATSC_AUTO) && (0.0 <= me);
     uint32_t best_size = 0xFFFFFFFFu;
     int best_owner = 3;  // 0 FFT, 1 Polynomial, 2 RLE: the tie order of frame/mod.rs:77
     auto can_win = [&](uint32_t size_lb, int owner) {
@@ -591,8 +613,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     if (run_rle) {
         // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
         uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
-        for (uint32_t j = tid; j < n; j += T)
-            if (j == 0 || xs[j] != xs[j - 1]) pk += (vlen(j) << 13) | 1u;
+        for_strided<FN, T>(tid, n, [&](uint32_t j) {
+            const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
+            if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
+        });
         pk = block_sum_u32<W>(pk, red, parity);
         rle_R = pk & 0x1fffu;
         rle_ib = pk >> 13;
@@ -621,6 +645,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
+    PH(2);
     if (!LEAN && prm.debug_stop == 10) return;
     // A payload below 19 bytes (FFT with one bin; Polynomial needs at least 23) already beats both
     // ladders: skip loading their operands.
@@ -640,6 +665,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
     }
 
+    PH(3);
     if (!LEAN && prm.debug_stop == 11) return;
     // ---- which ladder first: the one whose first payload is the smaller (FFT wins ties) ----
     bool poly_first = false;
@@ -655,7 +681,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             if (smax == smin) {
                 poly_K = 0;  // polynomial.rs:210-213
                 poly_step = 1;
-            } else if (!prm.bounded) {
+            } else if (!bounded) {
                 // Compressor::compress -> polynomial() -> compress_hinted(baseline points), no error loop
                 // (polynomial.rs:307-314,407-413)
                 poly_step = P.pstep[0];
@@ -836,6 +862,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     };
 
     if (poly_first) eval_poly();
+    PH(4);
     if (!LEAN && prm.debug_stop == 13) return;
     // =========================================================================================
     // FFT candidate: fft.rs:288-362
@@ -851,7 +878,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             rle_early = false;  // AB and the twiddle region (aux) are about to be overwritten
             {
                 const float2 *twp = twpool + P.tw_off;
-                for (uint32_t j = tid; j < L; j += T) tw[j] = twp[j];
+                for_strided<FIX ? (int)cL : 0, T>(tid, L, [&](uint32_t j) { tw[j] = twp[j]; });
             }
             float2 *spec;
             if (FIX && chalf) {
@@ -897,6 +924,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 __syncthreads();
                 spec = fft_forward<W>(P, A, B, tw);
             }
+            PH(5);
             if (!LEAN && prm.debug_stop == 4) return;
             // Order of admission: descending f32 norm = hypot(re, im) (fft.rs:88-106), ties by
             // ascending position.  W == 1: each lane keeps the norms of its KPL bins in registers
@@ -996,6 +1024,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 sorted_n = nk;
             }
 
+            PH(6);
             if (!LEAN && prm.debug_stop == 5) return;
             bool fft_pruned = false;
             float acc[SPL];
@@ -1013,7 +1042,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             double cur = prm.max_err + 1.0;
             // bounded: fft.rs:334 loop.  Unbounded (FFT::compress, fft.rs:366-388): one pass that only
             // admits the max(3, n/100) largest bins; nothing is reconstructed or measured.
-            while (prm.bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
+            while (bounded ? (prm.max_err_m < sat_i32(cur * 1000.0)) : (fft_trips == 0)) {
                 const uint32_t K = min(mf + jump, Z);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
@@ -1139,7 +1168,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         }
                     }
                 }
-                if (!prm.bounded) { cur = 0.0; break; }
+                PH(7);
+                if (!bounded) { cur = 0.0; break; }
                 double s = 0.0;
                 // fft.rs:208-218.  v is an f32, so v * 1e5 is exact (<= 41 significant bits) and
                 // round-half-away equals trunc(x + copysign(0.5, x)) (checked over the f32 range)
@@ -1166,6 +1196,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 }
                 s = block_sum_f64<W>(s, red, parity);
                 cur = s * invL;  // mean over the L padded samples (utils/error.rs:115); 1/L rounded once
+                PH(8);
                 if (fft_trips <= 17) jump += dk1;       // fft.rs:348-352
                 else if (fft_trips <= 22) jump += dk2;
                 else break;
@@ -1182,8 +1213,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
 
 
+    PH(9);
     if (!LEAN && prm.debug_stop == 14) return;
     if (!poly_first) eval_poly();
+    PH(10);
     if (!LEAN && prm.debug_stop == 15) return;
 
     // ---- RLE with many runs: exact size only if its bound can still win ----
@@ -1225,6 +1258,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
     dg.rle_size = rle_size;
 
+    PH(11);
     if (!LEAN && prm.debug_stop == 8) return;
     // =========================================================================================
     // selection: frame/mod.rs:113-147
@@ -1373,6 +1407,12 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         }
         out_len = hdr + hb + ibt;
     }
+    PH(12);
+#ifdef ATSC_STAMPS
+    __syncthreads();
+    if (W == 1 && FN != 0 && tid < 16) atomicAdd(&g_phase_cyc[(fid & 63u) * 16 + tid], ph_acc[tid]);
+    if (W == 1 && FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
     if (tid == 0) {
         res[fid].err = chosen_err;
         res[fid].len = out_len;
@@ -1716,7 +1756,8 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     // uniform launches of the power-of-two frame lengths the reference chunker emits (256 is also
     // BASELINE's framing) take the instantiation with the frame geometry folded in
-    const bool lean_ok = diag == nullptr && prm.debug_stop == 0 && !prm.trial && prm.trial_res == nullptr;
+    const bool lean_ok = diag == nullptr && prm.debug_stop == 0 && !prm.trial && prm.trial_res == nullptr &&
+                         prm.mode == ATSC_AUTO && prm.bounded && 0.0 <= prm.max_err;
     if (uni.enabled && lean_ok) {
         if constexpr (W == 1 && SPL == 5) {
             if (uni.n == 256) return launch_class2<1, 5, false, 256>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
@@ -1817,3 +1858,24 @@ hipError_t launch_order_by_cost(const uint32_t *ids_src, uint32_t *ids_dst, cons
 }
 
 }  // namespace atsc
+
+#ifdef ATSC_STAMPS
+extern "C" __attribute__((visibility("default"))) int atsc_dev_phase_read(unsigned long long *out16, int reset)
+{
+    static unsigned long long rows[64 * 16];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(atsc::g_phase_cyc), sizeof(rows)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) {
+        out16[i] = 0;
+        for (int r = 0; r < 64; ++r) out16[i] += rows[r * 16 + i];
+    }
+    if (reset) {
+        for (auto &v : rows) v = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(atsc::g_phase_cyc), rows, sizeof(rows)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int atsc_dev_span_read(unsigned long long *out, unsigned n_frames)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(atsc::g_frame_span), sizeof(unsigned long long) * 2 * n_frames) == hipSuccess ? 0 : -1;
+}
+#endif
