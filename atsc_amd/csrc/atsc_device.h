@@ -222,9 +222,10 @@ DEVI double wave_sum_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-// for (j = tid; j < n; j += T) f(j) -- with a compile-time length FN (0: not fixed) the trips are unrolled, so
-// that the loads of all trips issue together instead of one LDS round trip per (divergent) loop trip.
-template <int FN, int T, typename F>
+// for (j = tid; j < n; j += T) f(j), unrolled: FN trips for a compile-time length FN, else MAXIT predicated
+// trips (n <= MAXIT * T by the caller's contract; MAXIT = 0: plain loop).  Unrolled, the loads of all trips
+// issue together instead of one LDS round trip per (divergent) loop trip.
+template <int FN, int T, int MAXIT = 0, typename F>
 DEVI void for_strided(uint32_t tid, uint32_t n, F &&f)
 {
     if constexpr (FN != 0) {
@@ -232,6 +233,12 @@ DEVI void for_strided(uint32_t tid, uint32_t n, F &&f)
         for (int m = 0; m < (FN + T - 1) / T; ++m) {
             const uint32_t j = tid + (uint32_t)(m * T);
             if (FN % T == 0 || j < (uint32_t)FN) f(j);
+        }
+    } else if constexpr (MAXIT != 0) {
+#pragma unroll
+        for (int m = 0; m < MAXIT; ++m) {
+            const uint32_t j = tid + (uint32_t)(m * T);
+            if (j < n) f(j);
         }
     } else {
         for (uint32_t j = tid; j < n; j += T) f(j);

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
             const double2 *src2 = (const double2 *)src;
             double2 *xs2 = (double2 *)xs;
-            for_strided<FN / 2, T>(tid, n >> 1, [&](uint32_t j) { xs2[j] = src2[j]; });
+            for_strided<FN / 2, T, (SPL + 1) / 2>(tid, n >> 1, [&](uint32_t j) { xs2[j] = src2[j]; });
         } else {
             for (uint32_t j = tid; j < n; j += T) xs[j] = src[j];
         }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         const double x0 = xs[0];
         double mn = x0, mx = x0;
         uint32_t fr_any = 0;
-        for_strided<FN, T>(tid, n, [&](uint32_t j) {
+        for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
             const double v = xs[j];
             fr_any |= frac_nonzero(v) ? 1u : 0u;
             if (v > mx) mx = v;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         smax = mx;
         if (mn == 0.0 || mx == 0.0) {
             uint32_t mni = 0xFFFFFFFFu, mxi = 0xFFFFFFFFu;
-            for_strided<FN, T>(tid, n, [&](uint32_t j) {
+            for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
                 const double v = xs[j];
                 if (v == mn) mni = min(mni, j);
                 if (v == mx) mxi = min(mxi, j);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     if (run_rle) {
         // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
         uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
-        for_strided<FN, T>(tid, n, [&](uint32_t j) {
+        for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
             const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
             if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
         });
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             rle_early = false;  // AB and the twiddle region (aux) are about to be overwritten
             {
                 const float2 *twp = twpool + P.tw_off;
-                for_strided<FIX ? (int)cL : 0, T>(tid, L, [&](uint32_t j) { tw[j] = twp[j]; });
+                for_strided<FIX ? (int)cL : 0, T, SPL>(tid, L, [&](uint32_t j) { tw[j] = twp[j]; });
             }
             float2 *spec;
             if (FIX && chalf) {
