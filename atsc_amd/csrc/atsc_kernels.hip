@@ -259,8 +259,8 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // one-wavefront kernel.  A frame sums its phases in LDS (128 static bytes: 22 instead of 23 frames per CU) and
 // adds them to one of 64 global rows when it ends.
 __device__ unsigned long long g_phase_cyc[64 * 16];
-__device__ unsigned long long g_frame_span[65536 * 2];  // wall clock (100 MHz) at a frame's start and end, by launch slot
-#define PH(i) do { if (W == 1 && FN != 0) { const long long now_ = clock64(); \
+__device__ unsigned long long g_frame_span[65536 * 3];  // wall clock (100 MHz) at a frame's start and end, by launch slot; HW_ID | XCC_ID << 32
+#define PH(i) do { if (FN != 0) { const long long now_ = clock64(); \
     if (tid == 0) atomicAdd(&ph_acc[i], (unsigned long long)(now_ - ph_t)); ph_t = clock64(); } } while (0)
 #else
 #define PH(i) do {} while (0)
@@ -286,7 +286,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     if (tid < 16) ph_acc[tid] = 0;
     __syncthreads();
     long long ph_t = clock64();
-    if (W == 1 && FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[2 * blockIdx.x] = wall_clock64();
+    if (FN != 0 && tid == 0 && blockIdx.x < 65536) {
+        g_frame_span[3 * blockIdx.x] = wall_clock64();
+        g_frame_span[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+                                           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
+    }
 #endif
     if (uni.enabled) {
         const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0 : blockIdx.x;
@@ -964,24 +968,39 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 __syncthreads();
             }
             const uint32_t Z = block_sum_u32<W>(nz, red, parity);  // fft.rs:249-252 zero cut-off
-            if (W > 1) {
-                // The ladder can admit kcap bins at most.  The keys are distinct (the position is
-                // part of the key), so the kcap smallest ones are exactly those <= the kcap-th smallest
-                // key: an 8-bit radix select finds it in six counting passes (key bits 16..31 are zero),
-                // the survivors move to the front, and only they are sorted.
+            // W > 1: the order of admission is built when the ladder asks for it, and in two stages.  Most frames end
+            // within their first trips, so the first stage orders the bins three trips can take (mf + 2 dk1); a ladder
+            // that goes on gets the full order of the kcap bins it can admit at most.  Either way: the keys are
+            // distinct (the position is part of the key), so the `want` smallest ones are exactly those <= the want-th
+            // smallest key.  An 8-bit radix select closes in on it digit by digit (key bits 16..31 are zero: six
+            // counting passes at most) and stops as soon as the bins above the digit plus the bins in it are few enough
+            // to sort -- typically after the two leading bytes of the norm; every key up to the digit moves to the
+            // front and is sorted: keys[0 .. sorted_n) is the complete head of the (norm desc, position asc) order.
+            bool keys_fresh = true;  // keys[] holds every bin (as the norm pass left it)
+            auto build_order = [&](const uint32_t want) {
+                if (!keys_fresh) {
+                    __syncthreads();
+                    for (uint32_t k = tid; k < bins; k += T) {
+                        const float2 z = spec[k];
+                        const float nrm = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                        keys[k] = ((uint64_t)(~__float_as_uint(nrm)) << 32) | (uint64_t)k;
+                    }
+                    __syncthreads();
+                }
+                keys_fresh = false;
                 uint32_t nk = bins;
-                if (bins > kcap && kcap > 0) {
-                    uint32_t *hist = (uint32_t *)(smem + o_hist);  // 256 counters, then {digit, below, count}
-                    uint64_t prefix = 0;
-                    uint32_t remaining = kcap;
+                if (bins > want && want > 0) {
+                    uint32_t *hist = (uint32_t *)(smem + o_hist);  // 256 counters, then {digit, below, count, in digit}
+                    const uint32_t few = 2 * want + 16;
+                    uint64_t prefix = 0, resolved = 0;
+                    uint32_t remaining = want;
                     for (int shift = 56; shift >= 0; shift -= 8) {
                         if (shift == 24 || shift == 16) continue;
                         for (uint32_t i = tid; i < 256; i += T) hist[i] = 0;
                         __syncthreads();
-                        const uint64_t himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
                         for (uint32_t k = tid; k < bins; k += T) {
                             const uint64_t v = keys[k];
-                            if ((v & himask) == prefix) atomicAdd(&hist[(uint32_t)(v >> shift) & 255u], 1u);
+                            if ((v & resolved) == prefix) atomicAdd(&hist[(uint32_t)(v >> shift) & 255u], 1u);
                         }
                         __syncthreads();
                         if (tid < 64) {  // first digit whose running count reaches `remaining`
@@ -990,18 +1009,22 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                             const uint32_t incl = wave_incl_scan_u32(sum);
                             const uint64_t reach = __ballot(incl >= remaining);
                             if (reach && tid == (uint32_t)__builtin_ctzll(reach)) {
-                                uint32_t cum = incl - sum, d = 4 * tid;
-                                if (cum + c0 < remaining) { cum += c0; ++d;
-                                    if (cum + c1 < remaining) { cum += c1; ++d;
-                                        if (cum + c2 < remaining) { cum += c2; ++d; } } }
+                                uint32_t cum = incl - sum, d = 4 * tid, in = c0;
+                                if (cum + c0 < remaining) { cum += c0; ++d; in = c1;
+                                    if (cum + c1 < remaining) { cum += c1; ++d; in = c2;
+                                        if (cum + c2 < remaining) { cum += c2; ++d; in = c3; } } }
                                 hist[256] = d;
                                 hist[257] = cum;
+                                hist[259] = in;
                             }
                         }
                         __syncthreads();
                         prefix |= (uint64_t)hist[256] << shift;
+                        resolved |= 0xffull << shift;
                         remaining -= hist[257];
+                        nk = (want - remaining) + hist[259];  // bins above the digit, bins in it
                         __syncthreads();
+                        if (nk <= few) break;
                     }
                     constexpr int KPT = SPL / 2 + 1;  // bins <= 32 * W * SPL + 1
                     uint64_t mine[KPT];
@@ -1014,15 +1037,14 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     __syncthreads();
 #pragma unroll
                     for (int c = 0; c < KPT; ++c)
-                        if (mine[c] <= prefix) keys[atomicAdd(&hist[258], 1u)] = mine[c];
+                        if ((mine[c] & resolved) <= prefix) keys[atomicAdd(&hist[258], 1u)] = mine[c];
                     __syncthreads();
-                    nk = kcap;
                 }
                 uint32_t p2 = 1;
                 while (p2 < nk) p2 <<= 1;
                 block_sort<W, true>(keys, nullptr, nk, p2);
                 sorted_n = nk;
-            }
+            };
 
             PH(6);
             if (!LEAN && prm.debug_stop == 5) return;
@@ -1046,6 +1068,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 const uint32_t K = min(mf + jump, Z);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
+                if (W > 1 && !heap_order && K > sorted_n) {
+                    const uint32_t first = mf + 2 * dk1;
+                    build_order((K <= first && first < kcap) ? first : kcap);
+                }
                 if (W > 1 && !heap_order) {
                     // Bit-equal norms among the bins this trip admits, or between the last of them and the next
                     // one in line: the reference's order there is the BinaryHeap's, not (norm, position).  The
@@ -1410,8 +1436,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     PH(12);
 #ifdef ATSC_STAMPS
     __syncthreads();
-    if (W == 1 && FN != 0 && tid < 16) atomicAdd(&g_phase_cyc[(fid & 63u) * 16 + tid], ph_acc[tid]);
-    if (W == 1 && FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[2 * blockIdx.x + 1] = wall_clock64();
+    if (FN != 0 && tid < 16) atomicAdd(&g_phase_cyc[(fid & 63u) * 16 + tid], ph_acc[tid]);
+    if (FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[3 * blockIdx.x + 1] = wall_clock64();
 #endif
     if (tid == 0) {
         res[fid].err = chosen_err;
@@ -1876,6 +1902,6 @@ extern "C" __attribute__((visibility("default"))) int atsc_dev_phase_read(unsign
 }
 extern "C" __attribute__((visibility("default"))) int atsc_dev_span_read(unsigned long long *out, unsigned n_frames)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(atsc::g_frame_span), sizeof(unsigned long long) * 2 * n_frames) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(atsc::g_frame_span), sizeof(unsigned long long) * 3 * n_frames) == hipSuccess ? 0 : -1;
 }
 #endif
