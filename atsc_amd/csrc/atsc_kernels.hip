@@ -1119,6 +1119,51 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     hlen = bins - K;
                     __syncthreads();
                 }
+                if constexpr (W >= 8) {  // (W == 4: the extra registers would cost a workgroup per CU)
+                    // The trip's bins are staged first: thread i looks bin i up (order -> position -> spectrum), files
+                    // it in sel[] and leaves its position, its coefficient (fft.rs:401-422 mirror: bin 0 and, for even
+                    // L, bin L/2 contribute once; the 1/L of fft.rs:343 is folded in) and its twiddle stride in LDS.
+                    // Every thread then walks the staged list: one uniform LDS read per bin instead of three dependent
+                    // round trips, and the f64 coefficient arithmetic once per bin instead of once per wavefront.
+                    struct Stg { uint32_t pos, stp; float a, b; };
+                    Stg *stg = (Stg *)(smem + o_hist);  // 1040 bytes: 64 entries (the radix select is done with them)
+                    // (a handful of bins -- the later trips of a 1024-sample frame -- are quicker one by one, below)
+                    while (K - used >= 8) {
+                        const uint32_t cnt = min(K - used, 64u);
+                        __syncthreads();
+                        if (tid < cnt) {
+                            const uint32_t i = used + tid;
+                            const uint32_t pos = (uint32_t)(keys[heap_order ? bins - 1 - i : i] & 0xffffffffu);
+                            const float2 z = spec[pos];
+                            sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
+                            const double cf = ((pos == 0 || 2 * pos == L) ? 1.0 : 2.0) * invL;
+                            Stg e;
+                            e.pos = pos;
+                            e.stp = mod_magic(pos * (uint32_t)T, L, magicL);
+                            e.a = (float)(cf * (double)z.x);
+                            e.b = (float)(cf * (double)z.y);
+                            stg[tid] = e;
+                        }
+                        __syncthreads();
+#pragma unroll 2
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            const Stg e = stg[i];
+                            const bool isdc = e.pos == 0;  // its share is added at evaluation time (acc + dc)
+                            dc = isdc ? e.a : dc;
+                            const float a = isdc ? 0.0f : e.a, b = isdc ? 0.0f : e.b;
+                            uint32_t idx = mod_magic(e.pos * tid, L, magicL);
+#pragma unroll
+                            for (int m = 0; m < SPL; ++m) {
+                                const float2 w = tw[idx];
+                                acc[m] = fmaf(a, w.x, acc[m]);
+                                acc[m] = fmaf(-b, w.y, acc[m]);
+                                idx += e.stp;
+                                idx = min(idx, idx - L);  // idx < 2L: unsigned wrap picks the reduced value
+                            }
+                        }
+                        used += cnt;
+                    }
+                }
                 for (; used < K; ++used) {
                     uint32_t pos;
                     float2 z;
@@ -1229,6 +1274,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
             }
             fft_err = cur;
             fft_k = used;
+            if (W > 1) {  // positions that take a three-byte varint
+                uint32_t b3 = 0;
+                for (uint32_t i = tid; i < used; i += T) b3 += (sel[i].pos >= 251) ? 1u : 0u;
+                big = block_sum_u32<W>(b3, red, parity);
+            }
             fft_size = 1 + vlen(used) + 9 * used + 2 * big + 8;
             fft_done = !fft_pruned;
             __syncthreads();  // sel[] is complete; AB may be reused from here on
