@@ -543,10 +543,20 @@ extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
 // the launch of the frame class that holds the most frames.
 extern "C" int atsc_ctx_set_profiling(atsc_ctx *ctx, int on)
 {
+    ATSC_API_BEGIN
     if (!ctx) return ATSC_E_INVALID;
     ctx->profiling = on != 0;
     ctx->ev_used = 0;
+    // the event pairs of the first timed launches exist before the first of them (creating an event takes tens of
+    // microseconds now and then: not inside a region the caller is timing)
+    while (on && ctx->ev_pool.size() < 64) {
+        hipEvent_t a, b;
+        HIPCHK(ctx, hipEventCreate(&a));
+        HIPCHK(ctx, hipEventCreate(&b));
+        ctx->ev_pool.emplace_back(a, b);
+    }
     return ATSC_OK;
+    ATSC_API_END
 }
 extern "C" int atsc_ctx_profile_read(atsc_ctx *ctx, double *total_ms, uint64_t *launches)
 {
