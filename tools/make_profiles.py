@@ -23,7 +23,7 @@ for name in ("bench", "stats_bench", "bench_share2"):
         lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
         if lines:
             open(os.path.join(P, "%s_%s.json" % (tag, name)), "w").write(lines[-1] + "\n")
-for name in ("other_configs", "config3_full_1gpu", "length_probe"):
+for name in ("other_configs", "config3_full_1gpu", "length_probe", "stamps_256", "stamps_2048", "stamps_4096", "queue_probe"):
     src = os.path.join(G, "%s_%s.txt" % (tag, name))
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().splitlines() if "amdgpu.ids" not in l)
