@@ -268,7 +268,7 @@ __device__ unsigned long long g_frame_span[65536 * 3];  // wall clock (100 MHz) 
 // one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs).
 // FN != 0: every frame of the launch has FN samples (FN >= 128, even transform length) and the frame
 // geometry is folded at compile time; FN == 0 reads it from the per-length table.
-template <int W, int SPL, bool IDW, int FN>
+template <int W, int SPL, bool IDW, int FN, bool LEAN_ = (FN != 0)>
 __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void k_compress(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     // sample-level trial (launch_class routes those calls to the table-driven instantiation).  Their
     // bookkeeping would otherwise sit in scalar registers for the whole kernel.  They also only serve the auto
     // selector with an error bound >= 0 (`atsc -e`, BASELINE's configurations): mode, bounded and prune fold.
-    constexpr bool LEAN = FIX;
+    constexpr bool LEAN = LEAN_;  // (every fixed-length instantiation is lean; the table-driven ones come in both forms)
+    static_assert(LEAN || !FIX, "fixed-length instantiations are lean");
     constexpr uint32_t cL = FIX ? cx_next_size(FIX ? FN : 1) : 0, cmf = (3 >= FN / 100) ? 3 : FN / 100;
     static_assert(!FIX || (FN >= 128 && cL <= 64 * W * SPL), "fixed-length instantiation");
     constexpr bool chalf = cL % 2 == 0;              // even L: packed real transform of length L / 2
@@ -1796,7 +1797,7 @@ hipError_t launch_nonfinite_flag(const double *x, uint64_t n, uint32_t *flag, hi
 // --------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------
-template <int W, int SPL, bool IDW, int FN>
+template <int W, int SPL, bool IDW, int FN, bool LEAN_ = (FN != 0)>
 static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samples,
                                const DevFrame *frames, const uint32_t *ids, const DevPlan *plans,
                                const float2 *twpool, const KParams &prm, uint8_t *slots,
@@ -1804,7 +1805,7 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
                                hipEvent_t ev0, hipEvent_t ev1)
 {
     if (count == 0) return hipSuccess;
-    auto kern = k_compress<W, SPL, IDW, FN>;
+    auto kern = k_compress<W, SPL, IDW, FN, LEAN_>;
     static const uint32_t lds_pad = [] {  // ATSC_DEBUG_LDS_PAD: occupancy experiments only, read once
         const char *pad = getenv("ATSC_DEBUG_LDS_PAD");
         return pad ? (uint32_t)atoi(pad) : 0u;
@@ -1852,6 +1853,10 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
             if (uni.n == 4096) return launch_class2<16, 5, false, 4096>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
         }
     }
+    // any other length under the auto selector: the table-driven kernel without the forced-codec / trial /
+    // diagnostics paths
+    if (lean_ok)
+        return launch_class2<W, SPL, false, 0, true>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     return launch_class2<W, SPL, false, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
 }
 
