@@ -273,6 +273,7 @@ def main():
                     help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
                          "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
     ap.add_argument("--no-chains", action="store_true", help="skip the several-chains measurement (N = 1)")
+    ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
     ap.add_argument("--no-adaptive-order", action="store_true",
                     help="start the frames in index order instead of costliest-first (cost = shader "
                          "clocks of the same frame slot in the previous step)")
@@ -498,6 +499,47 @@ def main():
                           "chain is the pipelined path `value` times on one" % CH}
         del cplan, couts, cctx
 
+    # BASELINE.json configs[4] beside it: every rank decodes the records it encoded, device resident (the frame
+    # table of the records is parsed once, untimed: atsc_dplan_create); no exchange of any kind on this path.
+    decomp = None
+    if not args.no_decompress:
+        o = outs2[0]
+        plan.compress(d_xs[0], o, atsc_amd.AUTO, True, me, 0, stream, pipelined=False)
+        torch.cuda.synchronize()
+        nb0 = int(o["rec_off"][-1].item())
+        dp = atsc_amd.DPlan(ctx, o["body"][:nb0].cpu().numpy())
+        d_out = torch.empty(n_local, dtype=torch.float64, device=dev)
+        for _ in range(2):
+            dp.decompress(o["body"], d_out, stream)
+        torch.cuda.synchronize()
+        # every frame's mean absolute percentage error is within the bound, so the batch's is
+        xin = d_xs[0]
+        nzm = xin != 0
+        mape = float(((d_out[nzm] - xin[nzm]).abs() / xin[nzm].abs()).sum().item()) / float(n_local)
+        if not (mape <= me * 1.0001 + 1e-9):
+            raise SystemExit("decoded batch misses the error bound: %r > %r" % (mape, me))
+        del nzm
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.decompress(o["body"], d_out, stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_dec = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_dec], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_dec = float(t.item())
+        decomp = {"metric": "Msamples/sec decompressed", "value": units_total * args.steps / dt_dec / 1e6,
+                  "unit": "Msamples/s", "ms_per_step": dt_dec * 1e3 / args.steps, "steps": args.steps,
+                  "batch_mape": mape,
+                  "config": "BASELINE.json configs[4]: every rank decodes the records of its own shard (device "
+                            "resident, frame table parsed once); no collective"}
+        del dp, d_out
+
     body_bytes = float(np.mean(body_bytes_b))
     if world > 1:
         t = torch.tensor([body_bytes_b[0]], dtype=torch.int64, device="cpu" if share else dev)
@@ -562,6 +604,8 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if decomp is not None:
+            out["decompress"] = decomp
         if value_no_hint is not None:
             out["value_no_hint"] = value_no_hint
             if chains is not None:
