@@ -655,6 +655,46 @@ def test_idw_one_131072_frame(ctx, A, oracle):
     assert s["tol"] == 0 and s["boundary"] == 0
 
 
+def test_independent_chains_on_one_gpu(ctx, A):
+    """Three chains -- a context, a plan and a stream each -- push batches through the pipelined entry point at the
+    same time (bench.py's `value_chains`, INTEGRATION.md "Several chains on one GPU"): every batch's bytes are those
+    of a plain call on one context, whatever the other chains' kernels were doing on the same CUs."""
+    import torch
+    import atsc_amd
+
+    dev = torch.device("cuda", 0)
+    nf, F = 4096, 256
+    off = H.frame_offsets(nf * F, F)
+    batches = [torch.from_numpy(H.synth_series(700 + b, nf * F)).to(dev) for b in range(4)]
+    plan = ctx.plan(off)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for d_x in batches:
+        plan.compress(d_x, o, A.AUTO, True, ME5, 0, stream)
+        torch.cuda.synchronize()
+        total = int(o["rec_off"][-1].item())
+        ref.append(o["body"][:total].cpu().numpy().tobytes())
+
+    C, rounds = 3, 4
+    ctxs = [atsc_amd.Context(0) for _ in range(C)]
+    plans = [c.plan(off) for c in ctxs]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
+    outs = [[p.alloc_outputs(torch, dev) for _ in range(rounds)] for p in plans]
+    for r in range(rounds):
+        for c in range(C):
+            plans[c].compress(batches[(r + c) % len(batches)], outs[c][r], A.AUTO, True, ME5, 0,
+                              streams[c].cuda_stream, pipelined=True)
+    for c in range(C):
+        plans[c].join(streams[c].cuda_stream)
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for c in range(C):
+            o = outs[c][r]
+            total = int(o["rec_off"][-1].item())
+            assert o["body"][:total].cpu().numpy().tobytes() == ref[(r + c) % len(batches)], (c, r)
+
+
 def test_pipelined_adaptive_order_mixed_lengths(ctx, A):
     """Cost-ordered launches (atsc_ctx_set_adaptive_order) over a plan with several frame-length
     classes and a large frame: eight pipelined batches, alternating between two data sets, give the
