@@ -677,7 +677,18 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     if (prune && run_fft && run_poly && smax != smin) {
         poly_first = poly_payload_size(P.pstep[0], P.pK[0]) < 1 + 1 + 9 * min(mf, bins) + 8;
     }
-    auto eval_poly = [&]() {
+    // The ladder runs in two goes when it runs first: its first trip before the FFT candidate, the rest after
+    // it.  A frame whose polynomial passes at once never transforms anything it does not have to; a frame whose
+    // first trip fails would otherwise walk the whole ladder unpruned (nothing passes yet) although the FFT
+    // candidate, a few trips later, stores less than the polynomial's next trips could: those are then pruned.
+    // Pruning only skips candidates that cannot win, so the selection does not depend on the order.  Only where it
+    // pays: 16-wavefront frames (n up to 4096: mf = 40 bins make the FFT's first payload 370 bytes, so the polynomial
+    // goes first on most frames, and every trip is a handful of barriers across the one workgroup a CU holds:
+    // 35 -> 40 Gsamples/s); smaller frames lose a little to the extra state (256: 110.5 -> 112 us).
+    constexpr bool POLY2GO = W >= 16;
+    double poly_cur = prm.max_err + 1.0;
+    bool poly_paused = false;
+    auto eval_poly = [&](const bool first_go) {
         // =========================================================================================
         // Polynomial (Catmull-Rom) candidate: polynomial.rs:209-277
         // =========================================================================================
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 const double inv_n = P.inv_n;
                 const bool pfast = fabs(smin) < 1e150 && fabs(smax) < 1e150;  // no overflow/NaN out of the spline
                 const bool nozero = smin > 0.0 || smax < 0.0;                  // every 1/|g| is finite
-                double cur = prm.max_err + 1.0;
+                double cur = POLY2GO ? poly_cur : prm.max_err + 1.0;
                 while (round(cur * 10000.0) > prm.poly_q_hi) {  // polynomial.rs:231: target < round(err, 4)
                     const uint32_t ti = poly_trips;  // 0 .. 22
                     const uint32_t step = P.pstep[ti];
@@ -854,6 +865,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                         break;
                     }
                     if (K == n) { cur = 0.0; break; }  // polynomial.rs:264-269
+                    if (POLY2GO && first_go && round(cur * 10000.0) > prm.poly_q_hi) {  // failed: the FFT candidate goes next
+                        poly_cur = cur;
+                        poly_paused = true;
+                        return;
+                    }
                 }
                 poly_err = cur;
             }
@@ -866,7 +882,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
 
     };
 
-    if (poly_first) eval_poly();
+    if (poly_first) eval_poly(true);
     PH(4);
     if (!LEAN && prm.debug_stop == 13) return;
     // =========================================================================================
@@ -1292,7 +1308,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
 
     PH(9);
     if (!LEAN && prm.debug_stop == 14) return;
-    if (!poly_first) eval_poly();
+    if (!poly_first || (POLY2GO && poly_paused)) eval_poly(false);
     PH(10);
     if (!LEAN && prm.debug_stop == 15) return;
 
