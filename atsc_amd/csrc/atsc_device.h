@@ -341,6 +341,7 @@ DEVI uint32_t block_min_u32(uint32_t v, double *red, int &parity)
 template <int W>
 DEVI uint32_t block_or_u32(uint32_t v, double *red, int &parity)
 {
+    if (W == 1) return __ballot(v != 0) ? 1u : 0u;  // one compare instead of a six-step DPP sum
     return block_sum_u32<W>(v ? 1u : 0u, red, parity) ? 1u : 0u;
 }
 // "fractional part is non-zero" exactly as optimizer/utils.rs:115-160 split_n(x).1 != 0.0 decides
