@@ -1811,6 +1811,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                         if (k0 + u * T < bins) atomicAdd(&h2[2047u - (v[u] >> 20)], 1u);
                 }
                 __syncthreads();
+                LT_STAMP("order: histogram");
                 {
                     const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
                     __syncthreads();
@@ -1820,6 +1821,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     if (a1 < kcap && a1 + c1 >= kcap) { bc[4] = 2 * tid + 1; bc[5] = a1; bc[6] = c1; }
                     __syncthreads();
                 }
+                LT_STAMP("order: digit found");
                 const uint32_t dstar = 2047u - bc[4], n_above = bc[5], n_cand = bc[6];
                 constexpr uint32_t CAND0 = LKEYS_MAX / 2;
                 __syncthreads();
@@ -1855,11 +1857,14 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                     }
                     }
                     __syncthreads();
+                    LT_STAMP("order: collected");
                     uint32_t pa = 1, pc = 1;
                     while (pa < n_above) pa <<= 1;
                     while (pc < n_cand) pc <<= 1;
                     block_sort<W, true>(keys, nullptr, n_above, pa);
+                    LT_STAMP("order: sorted above");
                     block_sort<W, true>(keys + CAND0, nullptr, n_cand, pc);
+                    LT_STAMP("order: sorted candidates");
                     const uint32_t take = kcap - n_above;  // 1 .. n_cand
                     for (uint32_t i = tid; i < n_above; i += T) spos[i] = (uint32_t)(keys[i] & 0xffffffffu);
                     for (uint32_t i = tid; i < take; i += T) spos[n_above + i] = (uint32_t)(keys[CAND0 + i] & 0xffffffffu);
