@@ -272,7 +272,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
                          "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
-    ap.add_argument("--no-chains", action="store_true", help="skip the several-chains measurement (N = 1)")
+    ap.add_argument("--chains", action="store_true",
+                    help="N = 1: also time the batches dealt over four independent chains (`value_chains`); the "
+                         "large-tier and host-pointer measurements are skipped in such a run (streams stay mapped "
+                         "to the few hardware queues once they exist: the measurements would disturb one another)")
     ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
     ap.add_argument("--no-adaptive-order", action="store_true",
                     help="start the frames in index order instead of costliest-first (cost = shader "
@@ -467,37 +470,39 @@ def main():
         dt_plain = timed_loop(args.steps, False)
         value_no_hint = units_total * args.steps / dt_plain / 1e6
 
-    # The same batches dealt round-robin over CHAINS independent chains -- a context, a plan and a stream each,
-    # nothing waits across them -- as a service with several request queues would drive one GPU.  A frame kernel's
-    # workgroups are short; a single hardware queue leaves a freed slot empty for a microsecond or two before the
-    # next one starts, and several queues keep the slots fuller (tools/queue_pipe_probe.py).  Reported beside
-    # `value`, which stays the single-chain figure the `roofline` launches belong to.
-    chains = None
-    if world == 1 and not args.no_chains:
-        CH = 4
-        cctx = [ctx] + [atsc_amd.Context(0) for _ in range(CH - 1)]
-        cplan = [plan] + [c.plan(off) for c in cctx[1:]]
-        couts = [outs2] + [[p.alloc_outputs(torch, dev), p.alloc_outputs(torch, dev)] for p in cplan[1:]]
-        cstream = [torch.cuda.Stream(device=dev) for _ in range(CH)]
+    def measure_chains():
+        # The same batches dealt round-robin over CHAINS independent chains -- a context, a plan and a stream each,
+        # nothing waits across them -- as a service with several request queues would drive one GPU.  A frame kernel's
+        # workgroups are short; a single hardware queue leaves a freed slot empty for a microsecond or two before the
+        # next one starts, and several queues keep the slots fuller (tools/queue_pipe_probe.py).  Reported beside
+        # `value`, which stays the single-chain figure the `roofline` launches belong to (--chains).
+        chains = None
+        if world == 1 and args.chains:
+            CH = 4
+            cctx = [ctx] + [atsc_amd.Context(0) for _ in range(CH - 1)]
+            cplan = [plan] + [c.plan(off) for c in cctx[1:]]
+            couts = [outs2] + [[p.alloc_outputs(torch, dev), p.alloc_outputs(torch, dev)] for p in cplan[1:]]
+            cstream = [torch.cuda.Stream(device=dev) for _ in range(CH)]
 
-        def cstep(i):
-            c = i % CH
-            cplan[c].compress(d_xs[i % R], couts[c][(i // CH) % 2], atsc_amd.AUTO, True, me, 0,
-                              cstream[c].cuda_stream, pipelined=True)
-        for i in range(8 * CH):
-            cstep(i)
-        torch.cuda.synchronize()
-        ksteps = max(args.steps, 16 * CH)  # its own count: long enough for the chains' ramp and drain not to weigh
-        t0 = time.perf_counter()
-        for i in range(ksteps):
-            cstep(i)
-        torch.cuda.synchronize()
-        dt_ch = time.perf_counter() - t0
-        chains = {"chains": CH, "value": units_total * ksteps / dt_ch / 1e6, "unit": "Msamples/s", "steps": ksteps,
-                  "ms_per_step": dt_ch * 1e3 / ksteps,
-                  "note": "batches round-robin over %d independent (context, plan, stream) chains on one GPU; each "
-                          "chain is the pipelined path `value` times on one" % CH}
-        del cplan, couts, cctx
+            def cstep(i):
+                c = i % CH
+                cplan[c].compress(d_xs[i % R], couts[c][(i // CH) % 2], atsc_amd.AUTO, True, me, 0,
+                                  cstream[c].cuda_stream, pipelined=True)
+            for i in range(8 * CH):
+                cstep(i)
+            torch.cuda.synchronize()
+            ksteps = max(args.steps, 16 * CH)  # its own count: long enough for the chains' ramp and drain not to weigh
+            t0 = time.perf_counter()
+            for i in range(ksteps):
+                cstep(i)
+            torch.cuda.synchronize()
+            dt_ch = time.perf_counter() - t0
+            chains = {"chains": CH, "value": units_total * ksteps / dt_ch / 1e6, "unit": "Msamples/s", "steps": ksteps,
+                      "ms_per_step": dt_ch * 1e3 / ksteps,
+                      "note": "batches round-robin over %d independent (context, plan, stream) chains on one GPU; each "
+                              "chain is the pipelined path `value` times on one" % CH}
+            del cplan, couts, cctx
+        return chains
 
     # BASELINE.json configs[4] beside it: every rank decodes the records it encoded, device resident (the frame
     # table of the records is parsed once, untimed: atsc_dplan_create); no exchange of any kind on this path.
@@ -608,8 +613,6 @@ def main():
             out["decompress"] = decomp
         if value_no_hint is not None:
             out["value_no_hint"] = value_no_hint
-            if chains is not None:
-                out["value_chains"] = chains
         vmod = os.path.join(ROOT, "profiles", "valu_model.json")
         if os.path.exists(vmod) and workload == "config2":
             try:
@@ -622,7 +625,9 @@ def main():
                 }
             except Exception:
                 pass
-        if world == 1 and workload == "config2" and not args.no_end_to_end:
+        if world == 1 and args.chains:
+            out["value_chains"] = measure_chains()
+        if world == 1 and workload == "config2" and not args.no_end_to_end and not args.chains:
             out["chunker_framing"] = chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream)
             out["end_to_end"] = end_to_end(ctx, atsc_amd, xs[0], off, me)
         if world == 1 and workload == "config2" and not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ def first(pattern):  # the newest match: gpurun merges every call's files into t
 f = first(os.path.join(G, tag + "_stats", "*", "*kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
-for name in ("bench", "stats_bench", "bench_share2"):
+for name in ("bench", "bench_chains", "stats_bench", "bench_share2"):
     src = os.path.join(G, "%s_%s.json" % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
