@@ -434,7 +434,10 @@ def main():
         # the flag is agreed by an all-reduce).
         ok = 1
         try:
-            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, max(body_bytes_b))
+            # (one resident batch per rank: every step encodes to the same bytes, so the agreed capacity needs no
+            # slack -- at N > 1 the step is bound by the bytes each link carries)
+            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, max(body_bytes_b),
+                                          slack=1.0 if R == 1 else 1.05)
             step(0)
             pg.drain()
             torch.cuda.synchronize()
