@@ -549,10 +549,12 @@ extern "C" int atsc_ctx_set_profiling(atsc_ctx *ctx, int on)
     ctx->ev_used = 0;
     // the event pairs of the first timed launches exist before the first of them (creating an event takes tens of
     // microseconds now and then: not inside a region the caller is timing)
+    // (device-scope release: the events only carry timestamps, and a system-scope release at the end of every timed
+    // dispatch is an L2 write-back between consecutive launches)
     while (on && ctx->ev_pool.size() < 64) {
         hipEvent_t a, b;
-        HIPCHK(ctx, hipEventCreate(&a));
-        HIPCHK(ctx, hipEventCreate(&b));
+        HIPCHK(ctx, hipEventCreateWithFlags(&a, hipEventReleaseToDevice));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b, hipEventReleaseToDevice));
         ctx->ev_pool.emplace_back(a, b);
     }
     return ATSC_OK;
@@ -1050,8 +1052,8 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         if (timed) {
             if (ctx->ev_used == ctx->ev_pool.size()) {
                 hipEvent_t a, b;
-                HIPCHK(ctx, hipEventCreate(&a));
-                HIPCHK(ctx, hipEventCreate(&b));
+                HIPCHK(ctx, hipEventCreateWithFlags(&a, hipEventReleaseToDevice));
+                HIPCHK(ctx, hipEventCreateWithFlags(&b, hipEventReleaseToDevice));
                 ctx->ev_pool.emplace_back(a, b);
             }
             ev0 = ctx->ev_pool[ctx->ev_used].first;
