@@ -315,17 +315,14 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         double acc[MAXS];
 #pragma unroll
         for (int m = 0; m < MAXS; ++m) acc[m] = 0.0;
-        for (uint32_t i = 0; i < K; ++i) {
-            const Sel e = sel[i];
-            const uint32_t pos = e.pos;
-            if (own[pos] != i + 1) continue;
+        auto add_entry = [&](const uint32_t pos, const float re, const float im) {
             if (pos == 0) {
 #pragma unroll
-                for (int m = 0; m < MAXS; ++m) acc[m] += (double)e.re;
-                continue;
+                for (int m = 0; m < MAXS; ++m) acc[m] += (double)re;
+                return;
             }
             const double cf = (2 * pos == L) ? 1.0 : 2.0;  // fft.rs:401-422
-            const double a = cf * (double)e.re, bq = cf * (double)e.im;
+            const double a = cf * (double)re, bq = cf * (double)im;
             uint32_t idx = mod_magic(pos * (tid + pre), L, magicL);  // pos * jj < 2^32
             const uint32_t stp = mod_magic(pos * (uint32_t)T, L, magicL);
 #pragma unroll
@@ -334,6 +331,32 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
                 acc[m] += a * (double)w.x - bq * (double)w.y;
                 idx += stp;
                 idx = min(idx, idx - L);  // idx < 2L: the unsigned wrap picks the reduced value
+            }
+        };
+        if (W == 1 && K <= 64) {
+            // one wavefront, at most one entry per lane: lane i looks entry i and its owner up once, and the walk
+            // takes position and value from lane i (v_readlane) -- two dependent LDS round trips per entry less
+            uint32_t e_pos = 0;
+            float e_re = 0.0f, e_im = 0.0f;
+            bool valid = false;
+            if (tid < K) {
+                const Sel e = sel[tid];
+                e_pos = e.pos; e_re = e.re; e_im = e.im;
+                valid = own[e.pos] == tid + 1;
+            }
+            uint64_t todo = __ballot(valid);
+            while (todo) {  // ascending entry index: the terms add up in stream order
+                const int i = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                add_entry((uint32_t)__builtin_amdgcn_readlane((int)e_pos, i),
+                          __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e_re), i)),
+                          __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e_im), i)));
+            }
+        } else {
+            for (uint32_t i = 0; i < K; ++i) {
+                const Sel e = sel[i];
+                if (own[e.pos] != i + 1) continue;
+                add_entry(e.pos, e.re, e.im);
             }
         }
 #pragma unroll
