@@ -1702,7 +1702,9 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
                                         large_sparse() ? 1 : 0, s,
                                         dp->large_pre.tiles1 ? &dp->large_pre : nullptr, dp->large_sp_tiles);
         else
-            e = launch_decompress(dp->d_frames, dp->n_frames, dp->d_ids + dp->class_first[c], c,
+            // (a class that holds every frame is walked in index order: no id lookup in front of the frame record)
+            e = launch_decompress(dp->d_frames, dp->n_frames,
+                                  dp->class_count[c] == dp->n_frames ? nullptr : dp->d_ids + dp->class_first[c], c,
                                   dp->class_count[c], dp->class_lds[c], dp->tabs.d_plans,
                                   dp->tabs.d_tw, d_body, d_out, dp->d_status, s);
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch k_decompress", e);
