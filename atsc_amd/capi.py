@@ -59,6 +59,8 @@ SIGNATURES = {
     "atsc_compress_plan_dev_pipelined": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int,
                                                    _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "atsc_plan_join": (C.c_int, [_vp, _vp, _vp]),
+    "atsc_plan_input_release": (C.c_int, [_vp, _vp, _vp]),
+    "atsc_ctx_set_chains": (C.c_int, [_vp, C.c_int]),
     "atsc_ctx_set_adaptive_order": (C.c_int, [_vp, C.c_int]),
     "atsc_ctx_enable_diag": (C.c_int, [_vp, C.c_int]),
     "atsc_ctx_last_diag": (C.c_int, [_vp, C.POINTER(FrameDiag), C.c_uint64]),

@@ -30,8 +30,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
                                  unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
-                                 const LargePre *pre = nullptr, hipStream_t s_frames = nullptr,
-                                 hipEvent_t ev_grids = nullptr, int *used_frames_stream = nullptr);
+                                 const LargePre *pre = nullptr);
 uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap);
 hipError_t launch_decompress_large(uint32_t count, const struct DevDFrame *frames, const uint32_t *ids,
                                    const DevPlan *plans, const float2 *twpool, const uint8_t *body,
@@ -75,9 +74,21 @@ struct atsc_ctx {
     std::vector<std::pair<void *, size_t>> pool_free_list;
     std::map<void *, size_t> pool_live;
     size_t pool_held = 0;
-    hipStream_t pack_stream = nullptr;  // created by the first pipelined call
-    hipStream_t frame_stream = nullptr; // pipelined calls: the large tier's per-frame kernels (launch_compress_large)
-    bool adaptive_order = true;         // pipelined calls start a class's costliest frames first
+    // Streams of the context's own (created on first use; few, because the runtime maps streams onto a handful of
+    // hardware queues).  Two uses:
+    //  * pipelined calls (atsc_compress_plan_dev_pipelined): consecutive batches go round-robin over the chains of a
+    //    plan, chain c on chain_streams[c] -- a dependent launch starts 6-10 us after its predecessor ends on this system
+    //    (tools/gap_probe.hip), and a frame kernel's freed wave slots refill slowly from a single queue; several queues
+    //    feeding the same CUs hide both (what bench.py --chains did from outside in round 2);
+    //  * the large tier: see large groups below.
+    hipStream_t chain_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t pack_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // a chain's packing: beside its next batch's codecs
+    int n_chains = 2;                   // atsc_ctx_set_chains / ATSC_CHAINS (1..4)
+    // The large tier's kernel chain is bound by latency, not by throughput (a chain of launches, several of them one
+    // workgroup per frame): the large frames of a call are dealt over LARGE_GROUPS contiguous groups, each on a stream
+    // of the context's own, forked from and joined to the caller's stream by events -- the groups' chains overlap.
+    // (the groups run on chain_streams[])
+    bool adaptive_order = false;        // pipelined calls start a class's costliest frames first (atsc_ctx_set_adaptive_order)
     int debug_stop = 0;  // ATSC_DEBUG_STOP: phase-timing aid for tools/, never set in production
     // optional timing of the dominant k_compress launch (HIP events on the launch stream)
     bool profiling = false;
@@ -139,28 +150,36 @@ struct atsc_plan {
     uint32_t ws_slots = 0;
     bool large_tiled = false;        // form of the large tier's in-kernel transforms
     LargePre large_pre{0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
-    // atsc_compress_plan_dev_pipelined: a second scratch set (allocated on first use) so that the
-    // packing of batch i (context's pack stream) overlaps the codecs of batch i+1 (caller's stream)
+    // atsc_compress_plan_dev_pipelined: consecutive calls go round-robin over up to four chains.  A chain is a stream
+    // of the context's (atsc_ctx::chain_streams) plus everything a batch in flight owns: scratch set (payload slots,
+    // results, scan scratch), large-tier workspace, cost records and the launch order derived from them.  Chain 0's
+    // scratch set is the plan's own (plain calls use it).
     struct Scratch {
         DevResult *d_res = nullptr;
         uint8_t *d_slots = nullptr;
         uint32_t *d_local = nullptr;
         uint64_t *d_blocksum = nullptr;
     };
-    mutable Scratch alt;
-    mutable int turn = 0;
-    mutable hipEvent_t ev_codec[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr};
-    mutable hipEvent_t ev_grids[2] = {nullptr, nullptr}, ev_frames[2] = {nullptr, nullptr};  // large tier on two streams
-    mutable unsigned char *d_ws_alt = nullptr;  // second workspace set of the large tier (pipelined calls)
-    mutable bool pack_pending[2] = {false, false};
+    struct Chain {
+        Scratch S;
+        unsigned char *d_ws = nullptr;      // large-tier workspace set
+        hipEvent_t ev_fork = nullptr;       // the caller's stream at the call
+        hipEvent_t ev_lfork = nullptr;      // large tier: this call's stream where the groups fork
+        hipEvent_t ev_codec = nullptr;      // every kernel that reads d_samples is done (atsc_plan_input_release)
+        hipEvent_t ev_done = nullptr;       // records packed (atsc_plan_join)
+        hipEvent_t ev_group[4] = {nullptr, nullptr, nullptr, nullptr};  // large tier: group chains done
+        bool pending = false;               // ev_done recorded and not yet known to have passed
+        // scheduling hint: clocks per frame in this chain's last batch and the launch order derived from them
+        uint32_t *d_cost = nullptr;
+        uint8_t *d_bucket = nullptr;
+        uint32_t *d_hist = nullptr;         // histogram + cursors of k_cost_hist / k_cost_scatter
+        uint32_t *d_ids_adapt = nullptr;
+        bool adapt_valid = false;
+        bool ready = false;
+    };
+    mutable Chain chains[8];  // two sets per chain stream: set q runs on stream q % (number of chains)
+    mutable uint32_t turn = 0;
     uint64_t slots_bytes = 0;
-    // scheduling hint of the pipelined path: clocks per frame in the last batch, and the launch
-    // order derived from them (one per scratch set; written by k_order_by_cost on the pack stream)
-    mutable uint32_t *d_cost = nullptr;
-    mutable uint8_t *d_bucket = nullptr;
-    mutable uint32_t *d_hist = nullptr;  // histogram + cursors of k_cost_hist / k_cost_scatter
-    mutable uint32_t *d_ids_adapt[2] = {nullptr, nullptr};
-    mutable bool adapt_valid[2] = {false, false};
 };
 
 struct atsc_dplan {
@@ -516,6 +535,8 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
     c->want_diag = getenv("ATSC_DIAG") != nullptr;
     if (const char *ds = getenv("ATSC_DEBUG_STOP")) c->debug_stop = atoi(ds);
     if (getenv("ATSC_NO_ADAPTIVE_ORDER")) c->adaptive_order = false;
+    if (getenv("ATSC_ADAPTIVE_ORDER")) c->adaptive_order = true;
+    if (const char *ch = getenv("ATSC_CHAINS")) c->n_chains = std::min(4, std::max(1, atoi(ch)));
     *out = c;
     return ATSC_OK;
     ATSC_API_END
@@ -528,8 +549,10 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
-    if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
-    if (ctx->frame_stream) (void)hipStreamDestroy(ctx->frame_stream);
+    for (auto &cs : ctx->chain_streams)
+        if (cs) (void)hipStreamDestroy(cs);
+    for (auto &cs : ctx->pack_streams)
+        if (cs) (void)hipStreamDestroy(cs);
     for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
     // blocks still held by plans that outlive their context (a contract violation) are left alone: their
     // owners would otherwise free them a second time
@@ -622,21 +645,25 @@ extern "C" void atsc_plan_destroy(atsc_plan *p)
     pool_free(p->ctx, p->d_local);
     pool_free(p->ctx, p->d_blocksum);
     pool_free(p->ctx, p->d_ws);
-    pool_free(p->ctx, p->d_ws_alt);
-    pool_free(p->ctx, p->alt.d_res);
-    pool_free(p->ctx, p->alt.d_slots);
-    pool_free(p->ctx, p->alt.d_local);
-    pool_free(p->ctx, p->alt.d_blocksum);
-    pool_free(p->ctx, p->d_cost);
-    pool_free(p->ctx, p->d_bucket);
-    pool_free(p->ctx, p->d_hist);
-    pool_free(p->ctx, p->d_ids_adapt[0]);
-    pool_free(p->ctx, p->d_ids_adapt[1]);
-    for (int k = 0; k < 2; ++k) {
-        if (p->ev_codec[k]) (void)hipEventDestroy(p->ev_codec[k]);
-        if (p->ev_pack[k]) (void)hipEventDestroy(p->ev_pack[k]);
-        if (p->ev_grids[k]) (void)hipEventDestroy(p->ev_grids[k]);
-        if (p->ev_frames[k]) (void)hipEventDestroy(p->ev_frames[k]);
+    for (int c = 0; c < 8; ++c) {
+        atsc_plan::Chain &ch = p->chains[c];
+        if (c > 0) {  // chain 0 borrows the plan's own scratch set and workspace
+            pool_free(p->ctx, ch.S.d_res);
+            pool_free(p->ctx, ch.S.d_slots);
+            pool_free(p->ctx, ch.S.d_local);
+            pool_free(p->ctx, ch.S.d_blocksum);
+            pool_free(p->ctx, ch.d_ws);
+        }
+        pool_free(p->ctx, ch.d_cost);
+        pool_free(p->ctx, ch.d_bucket);
+        pool_free(p->ctx, ch.d_hist);
+        pool_free(p->ctx, ch.d_ids_adapt);
+        if (ch.ev_fork) (void)hipEventDestroy(ch.ev_fork);
+        if (ch.ev_lfork) (void)hipEventDestroy(ch.ev_lfork);
+        if (ch.ev_codec) (void)hipEventDestroy(ch.ev_codec);
+        if (ch.ev_done) (void)hipEventDestroy(ch.ev_done);
+        for (int g = 0; g < 4; ++g)
+            if (ch.ev_group[g]) (void)hipEventDestroy(ch.ev_group[g]);
     }
     delete p;
 }
@@ -760,7 +787,8 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
     PCHK(pool_alloc(ctx, (void **)&p->d_local, n_frames * sizeof(uint32_t)));
     PCHK(pool_alloc(ctx, (void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
     if (p->class_count[CLASS_LARGE]) {
-        p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
+        // (a multiple of 4: the groups of a call get equal shares of the slots)
+        p->ws_slots = (std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS) + 3u) & ~3u;
         PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK
@@ -839,7 +867,7 @@ static int build_sub(atsc_ctx *ctx, const atsc_plan *plan, uint32_t min_n, uint3
 
 static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, const double *d_samples,
                       const KParams &prm, uint8_t *d_slots, DevResult *res, atsc_frame_diag *diag,
-                      hipStream_t s)
+                      hipStream_t s, unsigned char *d_ws)
 {
     UniArgs nouni;
     memset(&nouni, 0, sizeof(nouni));
@@ -852,7 +880,7 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
             lp.prefft = 0;
             e = launch_compress_large(t->class_count[c], d_samples, t->d_frames, t->d_ids + t->class_first[c],
                                       t->tabs.d_plans, t->tabs.d_tw, lp, d_slots, res, diag,
-                                      plan->d_ws, plan->ws_stride, plan->ws_slots, s);
+                                      d_ws, plan->ws_stride, plan->ws_slots, s);
         }
         else
             e = launch_compress_class(c, t->class_count[c], t->class_lds[c], d_samples, t->d_frames,
@@ -863,9 +891,54 @@ static int launch_sub(atsc_ctx *ctx, const atsc_plan *plan, const SubPlan *t, co
     return ATSC_OK;
 }
 
+// Streams and events a call needs from chain c; full: also the chain's scratch set, workspace and cost records
+// (pipelined calls; chain 0 borrows the plan's own scratch set).
+static int ensure_chain(atsc_ctx *ctx, const atsc_plan *plan, uint32_t c, bool full, uint32_t q)
+{
+    atsc_plan::Chain &ch = plan->chains[q];  // set q (scratch, events), run on chain stream c
+    if (!ctx->chain_streams[c]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->chain_streams[c], hipStreamNonBlocking));
+    if (full && !ctx->pack_streams[c]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_streams[c], hipStreamNonBlocking));
+    if (!ch.ev_fork) {
+        HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_lfork, hipEventDisableTiming));
+        // (ev_codec rides on the last k_compress dispatch as its stop event -- hipExtLaunchKernel -- when that is possible:
+        // a recorded marker between two codec launches opens a bubble of 10-20 us on the stream)
+        HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_codec, hipEventReleaseToDevice));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_done, hipEventDisableTiming));
+        for (int g = 0; g < 4; ++g) HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_group[g], hipEventDisableTiming));
+    }
+    if (q == 0 && !ch.S.d_res) {
+        ch.S.d_res = plan->d_res; ch.S.d_slots = plan->d_slots; ch.S.d_local = plan->d_local; ch.S.d_blocksum = plan->d_blocksum;
+        ch.d_ws = plan->d_ws;
+    }
+    if (!full || ch.ready) return ATSC_OK;
+    if (q > 0) {
+        const uint32_t nb = (uint32_t)((plan->n_frames + 1023) / 1024);
+        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_res, plan->n_frames * sizeof(DevResult)));
+        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_slots, plan->slots_bytes));
+        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_local, plan->n_frames * sizeof(uint32_t)));
+        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_blocksum, (nb + 1) * sizeof(uint64_t)));
+        if (plan->ws_slots) HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_ws, plan->ws_stride * plan->ws_slots));
+    }
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_cost, plan->n_frames * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(ch.d_cost, 0, plan->n_frames * sizeof(uint32_t)));
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_bucket, plan->n_frames));
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
+    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_ids_adapt, plan->n_frames * sizeof(uint32_t)));
+    ch.ready = true;
+    return ATSC_OK;
+}
+// chains a plan's pipelined calls rotate over: the context's setting, fewer when four scratch sets would be huge
+static uint32_t plan_chains(const atsc_ctx *ctx, const atsc_plan *plan)
+{
+    uint32_t nch = (uint32_t)ctx->n_chains;
+    while (nch > 1 && (plan->slots_bytes + plan->ws_stride * plan->ws_slots) * 2 * nch > (48ull << 30)) --nch;
+    return nch;
+}
+
 // Shared body of atsc_compress_plan_dev (pipelined == false: everything on `stream`, scratch set 0)
-// and atsc_compress_plan_dev_pipelined (codecs on `stream`, packing on the context's pack stream,
-// scratch sets alternate).
+// and atsc_compress_plan_dev_pipelined (the call's kernels, packing included, on the next chain's stream,
+// forked from `stream` by an event).
 static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
                          int compressor, int bounded, float max_error, int sample_level,
                          uint8_t *d_body, uint64_t body_cap, uint64_t *d_rec_off,
@@ -887,62 +960,65 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     default:
         return fail(ctx, ATSC_E_INVALID, "compress: unknown compressor id");
     }
-    hipStream_t s = (hipStream_t)stream;
-    atsc_plan::Scratch S;
-    S.d_res = plan->d_res; S.d_slots = plan->d_slots; S.d_local = plan->d_local; S.d_blocksum = plan->d_blocksum;
-    hipStream_t ps = s;  // stream of the packing kernels
-    int k = 0;
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t s = caller;  // the stream this call's kernels run on
+    uint32_t ci = 0, qi = 0; // chain (stream), set (scratch + events)
     if (pipelined) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
-        if (!ctx->pack_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking));
-        if (!plan->alt.d_res) {
-            const uint32_t nb = (uint32_t)((plan->n_frames + 1023) / 1024);
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_res, plan->n_frames * sizeof(DevResult)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_slots, plan->slots_bytes));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_local, plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->alt.d_blocksum, (nb + 1) * sizeof(uint64_t)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_cost, plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, hipMemset(plan->d_cost, 0, plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_bucket, plan->n_frames));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ids_adapt[0], plan->n_frames * sizeof(uint32_t)));
-            HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ids_adapt[1], plan->n_frames * sizeof(uint32_t)));
-            for (int i = 0; i < 2; ++i) {
-                // ev_codec rides on the last k_compress dispatch (hipExtLaunchKernel stop event)
-                HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_codec[i], hipEventReleaseToDevice));
-                HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_pack[i], hipEventDisableTiming | hipEventReleaseToDevice));
-            }
+        const uint32_t nch = plan_chains(ctx, plan);
+        qi = plan->turn % (2 * nch);  // two sets per chain: a chain's stream always holds a queued batch
+        ci = qi % nch;
+        plan->turn++;
+        // (every set is built by the first pipelined call: an allocation of hundreds of megabytes is milliseconds, not
+        // something to meet in the middle of a stream of batches)
+        for (uint32_t q = 0; q < 2 * nch; ++q) {
+            int rc = ensure_chain(ctx, plan, q % nch, true, q);
+            if (rc) return rc;
         }
-        k = plan->turn;
-        plan->turn ^= 1;
-        if (k) S = plan->alt;
-        ps = ctx->pack_stream;
-        // The packing that last read this scratch set (two calls ago) has to be done before the
-        // codecs overwrite it.  Waited for on the host: a marker on the codec stream would put a
-        // bubble of several microseconds between consecutive k_compress launches, and the host may
-        // still run two batches ahead of the GPU.
-        if (plan->pack_pending[k]) HIPCHK(ctx, hipEventSynchronize(plan->ev_pack[k]));
+        atsc_plan::Chain &ch = plan->chains[qi];
+        // The chain's previous batch owns this scratch set until its records are packed.  Its kernels precede this
+        // call's on the chain's stream, but the large tier's groups run on the other chains' streams as well; waiting
+        // on the host keeps that simple and bounds the host's run-ahead to one batch per chain.
+        if (ch.pending) HIPCHK(ctx, hipEventSynchronize(ch.ev_done));
+        ch.pending = false;
+        s = ctx->chain_streams[ci];
+        // Work the caller enqueued on `stream` before this call (the copy that brought d_samples, say) precedes the
+        // call's kernels.  An event record plus a cross-stream wait cost ~6 us of queue time per batch on this system,
+        // so they are only spent when `stream` still has work in flight.
+        if (hipStreamQuery(caller) != hipSuccess) {
+            (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: the launchers read the last error
+            HIPCHK(ctx, hipEventRecord(ch.ev_fork, caller));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ch.ev_fork, 0));
+        }
     } else {
-        // a plain call after pipelined ones: set 0 may still be read by the pack stream
-        for (int i = 0; i < 2; ++i)
-            if (plan->pack_pending[i]) {
-                HIPCHK(ctx, hipStreamWaitEvent(s, plan->ev_pack[i], 0));
-                plan->pack_pending[i] = false;
+        // a plain call after pipelined ones: the plan's own scratch set is chain 0's, and the caller expects stream
+        // order with everything enqueued before
+        for (int i = 0; i < 8; ++i)
+            if (plan->chains[i].pending) {
+                HIPCHK(ctx, hipStreamWaitEvent(s, plan->chains[i].ev_done, 0));
+                plan->chains[i].pending = false;
             }
     }
-    hipEvent_t codec_done = nullptr;  // already attached to the last codec dispatch, if any
-    hipEvent_t frames_event = nullptr;  // the large tier's per-frame kernels ran on the context's frame stream
+    atsc_plan::Chain &CH = plan->chains[qi];
+    atsc_plan::Scratch S;
+    S.d_res = plan->d_res; S.d_slots = plan->d_slots; S.d_local = plan->d_local; S.d_blocksum = plan->d_blocksum;
+    if (pipelined) S = CH.S;
+    uint32_t large_groups = 0;  // the large tier ran as this many group chains on the context's streams (CH.ev_group[])
     const bool adapt = pipelined && ctx->adaptive_order;
     bool want_order = false;  // set once the main launches (which record the costs) are enqueued
-    const uint32_t *ids_main = (adapt && plan->adapt_valid[k]) ? plan->d_ids_adapt[k] : plan->d_ids;
+    const uint32_t *ids_main = (adapt && CH.adapt_valid) ? CH.d_ids_adapt : plan->d_ids;
+    static const bool pack_apart = getenv("ATSC_PACK_SAME_STREAM") == nullptr;
+    bool codec_attached = false;  // ev_codec is the stop event of this call's last codec dispatch
     auto pack = [&]() -> int {
+        for (uint32_t g = 0; g < large_groups; ++g)
+            if (ctx->chain_streams[g] != s) HIPCHK(ctx, hipStreamWaitEvent(s, CH.ev_group[g], 0));
+        hipStream_t ps = s;
         if (pipelined) {
-            if (!codec_done) {
-                HIPCHK(ctx, hipEventRecord(plan->ev_codec[k], s));
-                codec_done = plan->ev_codec[k];
+            if (!codec_attached) HIPCHK(ctx, hipEventRecord(CH.ev_codec, s));  // nothing reads d_samples from here on
+            if (pack_apart) {  // the packing runs beside the chain's next codecs
+                ps = ctx->pack_streams[ci];
+                HIPCHK(ctx, hipStreamWaitEvent(ps, CH.ev_codec, 0));
             }
-            HIPCHK(ctx, hipStreamWaitEvent(ps, codec_done, 0));
-            if (frames_event) HIPCHK(ctx, hipStreamWaitEvent(ps, frames_event, 0));
         }
         hipError_t e = launch_pack(plan->d_frames, S.d_res, plan->n_frames, S.d_local, S.d_blocksum,
                                    S.d_slots, d_body, body_cap, d_rec_off, d_chosen, d_err,
@@ -950,15 +1026,15 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch pack", e);
         if (pipelined) {
             if (adapt && want_order) {
-                // launch order for the call after next (same scratch set): costliest frames first
-                e = launch_order_by_cost(plan->d_ids, plan->d_ids_adapt[k], plan->d_cost, plan->d_bucket,
-                                         plan->d_hist, plan->class_first.data(), plan->class_count.data(),
+                // launch order for this chain's next batch: costliest frames first
+                e = launch_order_by_cost(plan->d_ids, CH.d_ids_adapt, CH.d_cost, CH.d_bucket,
+                                         CH.d_hist, plan->class_first.data(), plan->class_count.data(),
                                          CLASS_LARGE, ps);
                 if (e != hipSuccess) return fail(ctx, ATSC_E_HIP, "launch order_by_cost", e);
-                plan->adapt_valid[k] = true;
+                CH.adapt_valid = true;
             }
-            HIPCHK(ctx, hipEventRecord(plan->ev_pack[k], ps));
-            plan->pack_pending[k] = true;
+            HIPCHK(ctx, hipEventRecord(CH.ev_done, ps));
+            CH.pending = true;
         }
         return ATSC_OK;
     };
@@ -1005,6 +1081,13 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.sparse_inv = large_sparse() ? 1u : 0u;
     prm.prefft = 0;
     prm.prestats = 0;
+    unsigned char *ws_set = pipelined ? CH.d_ws : plan->d_ws;  // large-tier workspace of this call
+    if (pipelined && ((compressor == ATSC_AUTO && sample_level > 0) || (compressor == ATSC_FFT && !bounded))) {
+        // the sub-plans below (trial prefixes, unpadded transforms) keep one result / table set per plan: such calls
+        // do not overlap with the other chains' batches
+        for (int i = 0; i < 8; ++i)
+            if ((uint32_t)i != qi && plan->chains[i].pending) HIPCHK(ctx, hipStreamWaitEvent(s, plan->chains[i].ev_done, 0));
+    }
     if (compressor == ATSC_AUTO && sample_level > 0) {
         if (!plan->trials[sample_level]) {
             SubPlan *t = nullptr;
@@ -1017,7 +1100,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         if (t->count) {
             KParams tp = prm;
             tp.trial = 1;
-            int rc = launch_sub(ctx, plan, t, d_samples, tp, S.d_slots, t->d_res, nullptr, s);
+            int rc = launch_sub(ctx, plan, t, d_samples, tp, S.d_slots, t->d_res, nullptr, s, ws_set);
             if (rc) return rc;
             prm.trial_res = t->d_res;
             prm.trial_min_n = t->min_n;
@@ -1032,12 +1115,12 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             if (rc) return rc;
             plan->nopad = t;
         }
-        int rc = launch_sub(ctx, plan, plan->nopad, d_samples, prm, S.d_slots, S.d_res, d_diag, s);
+        int rc = launch_sub(ctx, plan, plan->nopad, d_samples, prm, S.d_slots, S.d_res, d_diag, s, ws_set);
         if (rc) return rc;
         return pack();
     }
     int dominant = 0, last_c = 0;
-    if (adapt) { prm.cost = plan->d_cost; want_order = true; }
+    if (adapt) { prm.cost = CH.d_cost; want_order = true; }
     for (int c = 1; c < N_CLASSES; ++c)
         if (plan->class_count[c] > plan->class_count[dominant]) dominant = c;
     for (int c = 0; c < N_CLASSES; ++c)
@@ -1060,10 +1143,10 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             ev1 = ctx->ev_pool[ctx->ev_used].second;
             if (bracket) HIPCHK(ctx, hipEventRecord(ev0, s));
         }
-        if (pipelined && c == last_c && c != CLASS_LARGE) {
+        if (pipelined && c == last_c && c != CLASS_LARGE && !ev1) {
             // the packing waits for this dispatch's own completion event: no marker on the codec stream
-            if (!ev1) ev1 = plan->ev_codec[k];
-            codec_done = ev1;
+            ev1 = CH.ev_codec;
+            codec_attached = true;
         }
         hipError_t e;
         if (c == CLASS_LARGE) {
@@ -1072,35 +1155,49 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             // the pre-pass transforms every large frame; a trial launch or a forced codec other than
             // FFT / Auto would not use its results
             const bool pre = plan->large_pre.tiles1 && (compressor == ATSC_AUTO || compressor == ATSC_FFT);
-            unsigned char *ws = plan->d_ws;
-            hipStream_t sf = nullptr;
-            hipEvent_t evg = nullptr;
-            int on_frames = 0;
-            if (pipelined && pre && plan->class_count[c] <= plan->ws_slots && !getenv("ATSC_LARGE_ONE_STREAM")) {
-                // two workspace sets and a stream for the per-frame kernels: they overlap the next batch's grids
-                if (!ctx->frame_stream) {
-                    // (highest priority: these few latency-bound workgroups should start the moment their grids are done,
-                    // not queue behind the next batch's grid workgroups)
-                    int least = 0, greatest = 0;
-                    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-                    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->frame_stream, hipStreamNonBlocking, greatest));
+            const uint32_t cnt = plan->class_count[c];
+            // groups: contiguous shares of the large frames, each with its share of the workspace slots, on the
+            // context's chain streams (see atsc_ctx::chain_streams)
+            uint32_t G = 1;  // (measured: 80 frames of 131072 samples 0.45 ms as one chain, 0.50 as two, 0.73 as four)
+            if (const char *ge = getenv("ATSC_LARGE_GROUPS")) G = (uint32_t)std::min(4, std::max(1, atoi(ge)));
+            if (ctx->debug_stop != 0 || ctx->want_diag) G = 1;  // the probes read one launch's output
+            G = std::min(G, cnt);
+            if (G <= 1) {
+                e = launch_compress_large(cnt, d_samples, plan->d_frames, plan->d_ids + plan->class_first[c],
+                                          plan->tabs.d_plans, plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag, ws_set,
+                                          plan->ws_stride, plan->ws_slots, s, pre ? &plan->large_pre : nullptr);
+            } else {
+                // group g runs on chain stream g, forked from this call's stream (which may be one of them)
+                for (uint32_t g = 0; g < G; ++g) {
+                    int rc = ensure_chain(ctx, plan, g, false, g);
+                    if (rc) return rc;
                 }
-                if (!plan->d_ws_alt) HIPCHK(ctx, pool_alloc(ctx, (void **)&plan->d_ws_alt, plan->ws_stride * plan->ws_slots));
-                for (int i = 0; i < 2; ++i) {
-                    if (!plan->ev_grids[i]) HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_grids[i], hipEventDisableTiming));
-                    if (!plan->ev_frames[i]) HIPCHK(ctx, hipEventCreateWithFlags(&plan->ev_frames[i], hipEventDisableTiming));
+                {
+                    int rc = ensure_chain(ctx, plan, ci, false, qi);
+                    if (rc) return rc;
                 }
-                if (k) ws = plan->d_ws_alt;
-                sf = ctx->frame_stream;
-                evg = plan->ev_grids[k];
-            }
-            e = launch_compress_large(plan->class_count[c], d_samples, plan->d_frames,
-                                      plan->d_ids + plan->class_first[c], plan->tabs.d_plans,
-                                      plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag, ws,
-                                      plan->ws_stride, plan->ws_slots, s, pre ? &plan->large_pre : nullptr, sf, evg, &on_frames);
-            if (e == hipSuccess && on_frames) {
-                HIPCHK(ctx, hipEventRecord(plan->ev_frames[k], ctx->frame_stream));
-                frames_event = plan->ev_frames[k];
+                hipEvent_t fork = CH.ev_lfork;
+                HIPCHK(ctx, hipEventRecord(fork, s));
+                const uint32_t per = (cnt + G - 1) / G, slots_g = plan->ws_slots / G;
+                e = hipSuccess;
+                uint32_t used = 0;
+                for (uint32_t g = 0; g < G; ++g) {
+                    const uint32_t g0 = g * per, g1 = std::min(cnt, g0 + per);
+                    if (g0 >= g1) break;
+                    hipStream_t ls = ctx->chain_streams[g];
+                    if (ls != s) HIPCHK(ctx, hipStreamWaitEvent(ls, fork, 0));
+                    e = launch_compress_large(g1 - g0, d_samples, plan->d_frames, plan->d_ids + plan->class_first[c] + g0,
+                                              plan->tabs.d_plans, plan->tabs.d_tw, lp, S.d_slots, S.d_res, d_diag,
+                                              ws_set + (uint64_t)g * slots_g * plan->ws_stride, plan->ws_stride, slots_g, ls,
+                                              pre ? &plan->large_pre : nullptr);
+                    if (e != hipSuccess) break;
+                    if (ls != s) HIPCHK(ctx, hipEventRecord(CH.ev_group[g], ls));
+                    ++used;
+                }
+                large_groups = used;
+                if (e == hipSuccess && bracket)  // the bracket's end event follows every group
+                    for (uint32_t g = 0; g < used; ++g)
+                        if (ctx->chain_streams[g] != s) HIPCHK(ctx, hipStreamWaitEvent(s, CH.ev_group[g], 0));
             }
         }
         else {
@@ -1148,8 +1245,21 @@ extern "C" int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on)
 extern "C" int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream)
 {
     if (!ctx || !plan) return fail(ctx, ATSC_E_INVALID, "plan_join: null argument");
-    for (int i = 0; i < 2; ++i)
-        if (plan->pack_pending[i]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, plan->ev_pack[i], 0));
+    for (int i = 0; i < 8; ++i)
+        if (plan->chains[i].pending) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, plan->chains[i].ev_done, 0));
+    return ATSC_OK;
+}
+extern "C" int atsc_plan_input_release(atsc_ctx *ctx, const atsc_plan *plan, void *stream)
+{
+    if (!ctx || !plan) return fail(ctx, ATSC_E_INVALID, "plan_input_release: null argument");
+    for (int i = 0; i < 8; ++i)
+        if (plan->chains[i].pending) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, plan->chains[i].ev_codec, 0));
+    return ATSC_OK;
+}
+extern "C" int atsc_ctx_set_chains(atsc_ctx *ctx, int n)
+{
+    if (!ctx || n < 1 || n > 4) return ATSC_E_INVALID;
+    ctx->n_chains = n;
     return ATSC_OK;
 }
 

@@ -2355,14 +2355,11 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
                                  unsigned char *ws, uint64_t ws_stride, uint32_t ws_slots, hipStream_t s,
-                                 const LargePre *pre, hipStream_t s_frames, hipEvent_t ev_grids, int *used_frames_stream)
+                                 const LargePre *pre)
 {
-    // s_frames / ev_grids (optional, pipelined calls): the per-frame kernels and the trip tiles of the few-frames
-    // form go to s_frames, behind an event recorded on s after the grids.  The per-frame kernels are
-    // latency-bound and hold 80 of 256 CUs; on a stream of their own they overlap the NEXT batch's grids (statistics,
-    // first polynomial trip, pre-pass) that the caller enqueues on s.  *used_frames_stream tells the caller to order the
-    // packing after s_frames.
-    if (used_frames_stream) *used_frames_stream = 0;
+    // (The caller deals the large frames of a batch over several streams, a contiguous group of frames and workspace
+    // slots each: the chain below is bound by latency -- a dependent launch starts 6-10 us after its predecessor ends on
+    // this system, tools/gap_probe.hip, and several links run one workgroup per frame -- so the groups' chains overlap.)
     const uint32_t lds = 384 + 1024 + 64 + max(8 * LKEYS_MAX, SP_LDS_BYTES);
     hipError_t e = ensure_dyn_lds((const void *)k_compress_large<0>, lds);
     if (e != hipSuccess) return e;
@@ -2413,14 +2410,6 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         }
         if (split) {
             hipStream_t sf = s;
-            if (s_frames && ev_grids && count <= ws_slots) {  // (one round only: a second round would reuse the workspace)
-                e = hipEventRecord(ev_grids, s);
-                if (e != hipSuccess) return e;
-                e = hipStreamWaitEvent(s_frames, ev_grids, 0);
-                if (e != hipSuccess) return e;
-                sf = s_frames;
-                if (used_frames_stream) *used_frames_stream = 1;
-            }
             hipLaunchKernelGGL(k_compress_large<1>, dim3(nb), dim3(LT), lds, sf, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, diag, ws, ws_stride);
             hipLaunchKernelGGL(k_large_trip_tiles, dim3((nb + 7u) & ~7u, pre->sp_tiles), dim3(LT), lds_tiles, sf, samples,

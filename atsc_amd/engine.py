@@ -48,6 +48,10 @@ class Context:
         """Pipelined calls start a class's costliest frames (previous batch's clocks) first."""
         capi.check(capi.lib().atsc_ctx_set_adaptive_order(self._h, int(on)), self._h)
 
+    def set_chains(self, n):
+        """Chains (context streams + scratch sets) the pipelined calls rotate over: 1..4."""
+        capi.check(capi.lib().atsc_ctx_set_chains(self._h, int(n)), self._h)
+
     def set_profiling(self, on=True):
         capi.check(capi.lib().atsc_ctx_set_profiling(self._h, int(on)), self._h)
 
@@ -135,8 +139,9 @@ class Plan:
     def compress(self, d_samples, outs, compressor=capi.AUTO, bounded=True, max_error=0.03, level=0,
                  stream=0, pipelined=False):
         """Enqueues the compression of every frame on `stream` (a raw hipStream_t or 0).
-        pipelined=True: atsc_compress_plan_dev_pipelined -- the record packing runs on the context's
-        own stream and overlaps the next call's codecs; `join(stream)` orders a stream after it."""
+        pipelined=True: atsc_compress_plan_dev_pipelined -- consecutive calls rotate over the plan's chains
+        (streams of the context's own); `join(stream)` orders a stream after their records,
+        `input_release(stream)` after their last read of d_samples."""
         assert d_samples.dtype.is_floating_point and d_samples.element_size() == 8
         assert d_samples.is_contiguous() and d_samples.numel() >= self.n_samples
         fn = capi.lib().atsc_compress_plan_dev_pipelined if pipelined else capi.lib().atsc_compress_plan_dev
@@ -149,8 +154,12 @@ class Plan:
         capi.check(rc, self.ctx._h)
 
     def join(self, stream=0):
-        """`stream` waits on the device for every pipelined packing enqueued so far."""
+        """`stream` waits on the device for every pipelined batch enqueued so far (records packed)."""
         capi.check(capi.lib().atsc_plan_join(self.ctx._h, self._h, C.c_void_p(stream)), self.ctx._h)
+
+    def input_release(self, stream=0):
+        """`stream` waits on the device until the pipelined calls enqueued so far have read their inputs."""
+        capi.check(capi.lib().atsc_plan_input_release(self.ctx._h, self._h, C.c_void_p(stream)), self.ctx._h)
 
 
 class DPlan:

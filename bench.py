@@ -209,7 +209,7 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
     sizes = atsc_amd.chunk_sizes(n)
     off = np.cumsum([0] + sizes).astype(np.uint64)
     plan = ctx.plan(off)
-    outs = [plan.alloc_outputs(torch, dev), plan.alloc_outputs(torch, dev)]
+    outs = [plan.alloc_outputs(torch, dev) for _ in range(4)]
     R = len(d_xs)
     for i in range(2):
         plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
@@ -222,14 +222,14 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
     dt_plain = (time.perf_counter() - t0) / reps
     total = int(outs[0]["rec_off"][-1].item())
     body = outs[0]["body"][:total].cpu().numpy().tobytes()
-    for i in range(4):
-        plan.compress(d_xs[i % R], outs[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+    for i in range(8):
+        plan.compress(d_xs[i % R], outs[i % 4], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
     plan.join(stream)
     torch.cuda.synchronize()
-    reps = 12
+    reps = 16
     t0 = time.perf_counter()
     for i in range(reps):
-        plan.compress(d_xs[i % R], outs[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+        plan.compress(d_xs[i % R], outs[i % 4], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
     plan.join(stream)
     torch.cuda.synchronize()
     dt_pipe = (time.perf_counter() - t0) / reps
@@ -277,9 +277,10 @@ def main():
                          "large-tier and host-pointer measurements are skipped in such a run (streams stay mapped "
                          "to the few hardware queues once they exist: the measurements would disturb one another)")
     ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
-    ap.add_argument("--no-adaptive-order", action="store_true",
-                    help="start the frames in index order instead of costliest-first (cost = shader "
-                         "clocks of the same frame slot in the previous step)")
+    ap.add_argument("--adaptive-order", action="store_true",
+                    help="start the frames costliest-first instead of in index order (cost = shader clocks of the same "
+                         "frame slot in an earlier batch of the same chain); off by default: with two chains in flight the "
+                         "drain of one launch is covered by the other chain's kernel and `value` leans on no hint")
     args = ap.parse_args()
 
     import torch
@@ -360,15 +361,15 @@ def main():
     # of step i runs on the context's pack stream and overlaps the frame codecs of step i+1 (and, for
     # N > 1, so does the gather of step i, issued from a side stream that waits for that packing).
     pipelined = not args.no_pipeline
-    if args.no_adaptive_order:
-        ctx.set_adaptive_order(False)
-    outs2 = [plan.alloc_outputs(torch, dev), plan.alloc_outputs(torch, dev)]
+    ctx.set_adaptive_order(bool(args.adaptive_order))
+    NOUT = 8  # output sets: one per batch in flight (the pipelined calls rotate over up to four chains)
+    outs2 = [plan.alloc_outputs(torch, dev) for _ in range(NOUT)]
     pg = None
     gstream = torch.cuda.Stream(device=dev) if world > 1 else None
     R = len(d_xs)
 
     def step(i, pipe=pipelined):
-        o = outs2[i % 2]
+        o = outs2[i % NOUT]
         if pg is not None:
             pg.before_produce(i % 2)
         plan.compress(d_xs[i % R], o, atsc_amd.AUTO, True, me, 0, stream, pipelined=pipe)
@@ -419,7 +420,9 @@ def main():
         torch.cuda.synchronize()
         body_bytes_b.append(int(outs2[0]["rec_off"][-1].item()))
     chosen = outs2[0]["chosen"].cpu().numpy()
-    for i in range(max(args.warmup, 1 if world > 1 else 0)):
+    # (at least one batch through every set of every chain: a set's first batch runs in index order, without the
+    # cost hint the steady state has)
+    for i in range(max(args.warmup, 2 * NOUT if pipelined else 0, 1 if world > 1 else 0)):
         step(i)
     if pipelined:
         plan.join(stream)
@@ -595,7 +598,7 @@ def main():
                 "gathered_bytes_last_step": gathered_sizes,
                 "pipeline": ("record packing of step i on the pack stream overlaps the codecs of step i+1 "
                              "(two scratch + output sets)" +
-                             ("" if args.no_adaptive_order else "; within a launch the frames start costliest "
+                             ("" if not args.adaptive_order else "; within a launch the frames start costliest "
                               "first, cost = shader clocks the same frame slot took two steps earlier (another batch)"))
                             if pipelined else "single stream",
             },

@@ -118,27 +118,42 @@ int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d
                            uint8_t *d_chosen, double *d_err, void *stream);
 
 /* The same call for back-to-back batches (a compression service's steady state; main.rs:146-163
- * run over file after file): the frame codecs are enqueued on `stream`, the packing of the records
- * into d_body on a stream owned by the context, with two scratch sets inside the plan, so that
- * packing batch i overlaps the codecs of batch i+1.  A call may block the host until the packing
- * enqueued two calls earlier has finished (its scratch set is reused); nothing else is
- * synchronised.  The outputs of a call are complete once a
- * stream has passed an atsc_plan_join enqueued after it (or after hipDeviceSynchronize); give
- * consecutive calls their own output buffers if batch i is still being read while batch i+1 is
- * packed.  atsc_compress_plan_dev may be mixed in; it orders itself after the pending packing. */
+ * run over file after file).  Consecutive calls on a plan go round-robin over up to four *chains*
+ * inside the plan: a stream owned by the context plus everything a batch in flight owns (payload
+ * slots, results, scan scratch, large-tier workspace).  A call's kernels -- codecs and packing -- run on
+ * its chain's stream, ordered after everything enqueued on `stream` before the call by one event, so
+ * up to four batches are in flight on as many hardware queues: the gap a single queue leaves between
+ * dependent launches (6-10 us here) and the slow refill of freed wave slots are hidden by the other
+ * chains' kernels.  Results are those of atsc_compress_plan_dev, byte for byte.
+ *   - A call may block the host until the batch that last used its chain (up to four calls
+ *     earlier) has finished; nothing else is synchronised.
+ *   - The outputs of a call are complete once a stream has passed an atsc_plan_join enqueued
+ *     after it (or after hipDeviceSynchronize).  Give the calls in flight their own output buffers.
+ *   - d_samples is read by kernels on the context's streams, NOT in `stream` order: it must not be
+ *     overwritten until a stream has passed an atsc_plan_input_release (or atsc_plan_join)
+ *     enqueued after the call.  (atsc_compress_plan_dev reads it in `stream` order; the large tier's
+ *     frames, which it also deals over the context's streams, are joined back before it returns.)
+ *   - atsc_compress_plan_dev may be mixed in; it orders itself after the pending batches. */
 int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan, const double *d_samples,
                                      int compressor, int bounded, float max_error,
                                      int sample_level, uint8_t *d_body, uint64_t body_cap,
                                      uint64_t *d_rec_off, uint8_t *d_chosen, double *d_err,
                                      void *stream);
+/* Chains the pipelined calls of this context rotate over (1..4, default 4; ATSC_CHAINS overrides the
+ * default).  1 keeps every batch on one stream of the context's. */
+int atsc_ctx_set_chains(atsc_ctx *ctx, int n);
 /* Pipelined calls record how many shader clocks every frame took and start the next batches of the
  * same plan with a class's costliest frames first (frame i of a recurring batch is the same series,
  * one window later); otherwise the frames that run longest start last and the GPU drains half
  * empty.  Only the order of execution changes, never a result.  On by default; 0 turns it off. */
 int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on);
-/* Makes `stream` wait (device side, no host block) for every packing enqueued so far by
- * atsc_compress_plan_dev_pipelined on `plan`. */
+/* Makes `stream` wait (device side, no host block) for every batch enqueued so far by
+ * atsc_compress_plan_dev_pipelined on `plan`: its records are packed. */
 int atsc_plan_join(atsc_ctx *ctx, const atsc_plan *plan, void *stream);
+/* Makes `stream` wait (device side) until no kernel of the pipelined calls enqueued so far on `plan`
+ * reads their d_samples any more: work enqueued on `stream` afterwards may overwrite the inputs
+ * (the reference's caller owns the chunk for the duration of compress_chunk_*, data.rs:47-76). */
+int atsc_plan_input_release(atsc_ctx *ctx, const atsc_plan *plan, void *stream);
 
 /* Per-frame diagnostics of the last atsc_compress_plan_dev on this ctx (host copy,
  * synchronises the stream).  One record per frame; used by the parity tests. */
