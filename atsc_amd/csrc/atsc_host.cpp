@@ -149,7 +149,7 @@ struct atsc_plan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;        // form of the large tier's in-kernel transforms
-    LargePre large_pre{0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
     // atsc_compress_plan_dev_pipelined: consecutive calls go round-robin over up to four chains.  A chain is a stream
     // of the context's (atsc_ctx::chain_streams) plus everything a batch in flight owns: scratch set (payload slots,
     // results, scan scratch), large-tier workspace, cost records and the launch order derived from them.  Chain 0's
@@ -194,7 +194,7 @@ struct atsc_dplan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;
-    LargePre large_pre{0, 0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
     uint32_t large_sp_tiles = 0;        // tiles per frame of the sparse inverse's (tile, frame) grid (0: off)
 };
 
@@ -308,11 +308,13 @@ static bool large_sparse() { return getenv("ATSC_LARGE_DENSE") == nullptr; }
 // the whole GPU before the per-frame kernel); all zero when a large frame length has no M1 x M2 split.
 static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
 {
-    LargePre pre{0, 0, 0, 0, 0, 0, 0};
+    LargePre pre{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool first_large = true;
     if (getenv("ATSC_LARGE_NO_PREPASS")) return pre;
+    pre.cols243 = getenv("ATSC_LARGE_OLD_COLS") ? 0u : 1u;
     for (uint32_t pi : large_plan_ids) {
         const DevPlan &p = plans[pi];
-        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0, 0};
+        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0, 0, 0, 0};
         pre.tiles1 = std::max(pre.tiles1, (p.f4_m2 + 15) / 16);
         pre.tiles2 = std::max(pre.tiles2, (p.f4_m1 + 15) / 16);
         pre.chunks = std::max(pre.chunks, (p.bins + 255) / 256);
@@ -320,6 +322,10 @@ static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::
         pre.m2_max = std::max(pre.m2_max, p.f4_m2);
         if (p.sp_mf) pre.sp_tiles = std::max(pre.sp_tiles, (p.sp_md + 7) / 8);
         pre.chunks_n = std::max(pre.chunks_n, (p.n + 4095) / 4096);
+        if (p.f4_m1 != 243) pre.cols243 = 0;
+        const uint32_t rp = (p.f4_m1 == 243 && p.f4_m2 == 288 && !getenv("ATSC_LARGE_OLD_ROWS")) ? 32u : 0u;
+        pre.rows9p = first_large ? rp : (pre.rows9p == rp ? rp : 0u);
+        first_large = false;
     }
     if (getenv("ATSC_LARGE_NO_TRIP_TILES")) pre.sp_tiles = 0;
     return pre;

@@ -132,6 +132,8 @@ struct LargePre {
     uint32_t m1_max, m2_max;          // longest sub-transforms: size the tile buffers in LDS
     uint32_t sp_tiles;                // most tiles (8 output columns each) the sparse inverse of a frame has
     uint32_t chunks_n;                // most 4096-sample chunks a frame has (k_large_stats, k_large_poly1)
+    uint32_t cols243;                 // 1: every large frame length splits as M = 243 x M2 (k_large_cols243)
+    uint32_t rows9p;                  // P when every large frame length has M2 = 9 P, P = 32 (k_large_rows9p), else 0
 };
 constexpr uint32_t LARGE_SPLIT_MAX = 128;  // large frames per launch up to which the first FFT trip's tiles
                                            // run as a (tile, frame) grid (launch_compress_large)

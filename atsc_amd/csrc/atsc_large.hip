@@ -939,6 +939,8 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
         if ((threadIdx.x & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
     }
 }
+#include "atsc_large_cols.h"
+
 // --------------------------------------------------------------------------------------------
 // k_compress_large
 // --------------------------------------------------------------------------------------------
@@ -2402,11 +2404,19 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                    plans, ws, ws_stride);
         }
         if (kp.prefft) {
-            hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples, frames,
-                               ids + b0, plans, twpool, ws, ws_stride);
+            if (pre->cols243)
+                hipLaunchKernelGGL(k_large_cols243, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0, plans,
+                                   twpool, ws, ws_stride);
+            else
+                hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples,
+                                   frames, ids + b0, plans, twpool, ws, ws_stride);
             const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
-            hipLaunchKernelGGL(k_large_pre23, dim3(tiles23, nb), dim3(PT), lds2, s, samples, frames, ids + b0, plans,
-                               twpool, ws, ws_stride, (int)kp.sparse_inv);
+            if (pre->cols243 && pre->rows9p == 32)
+                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
+                                   twpool, ws, ws_stride, (int)kp.sparse_inv);
+            else
+                hipLaunchKernelGGL(k_large_pre23, dim3(tiles23, nb), dim3(PT), lds2, s, samples, frames, ids + b0, plans,
+                                   twpool, ws, ws_stride, (int)kp.sparse_inv);
         }
         if (split) {
             hipStream_t sf = s;
