@@ -1087,6 +1087,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.sparse_inv = large_sparse() ? 1u : 0u;
     prm.prefft = 0;
     prm.prestats = 0;
+    prm.fast_skip = 0;
     unsigned char *ws_set = pipelined ? CH.d_ws : plan->d_ws;  // large-tier workspace of this call
     if (pipelined && ((compressor == ATSC_AUTO && sample_level > 0) || (compressor == ATSC_FFT && !bounded))) {
         // the sub-plans below (trial prefixes, unpadded transforms) keep one result / table set per plan: such calls

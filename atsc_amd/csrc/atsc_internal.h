@@ -122,6 +122,8 @@ struct KParams {
     uint32_t sparse_inv;         // large tier: per-trip inverse transform from the sparse bin list
     uint32_t prestats;           // large tier, split run: the statistics (LargeStats) and the chunk sums of the first
                                  // polynomial trip are in the frame's workspace slot (k_large_stats, k_large_poly1)
+    uint32_t fast_skip;          // large tier: k_compress_large<0> runs behind the fast path and skips the frames that
+                                 // path finished (FastState::status == 2)
     uint32_t prefft;             // large tier: forward transform, untangle and norms were done by the
                                  // batched pre-pass kernels (spectrum, norm bits and non-zero count are
                                  // in the frame's workspace slot)

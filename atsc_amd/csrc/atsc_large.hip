@@ -1150,6 +1150,18 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
     if (tid == 0) ((double *)(ws + lay.o_part))[blockIdx.x] = s;
 }
 
+// State of the fast path (atsc_large_fast.h)
+struct FastState {  // at LargeWs::o_front
+    uint32_t status;  // 0: left to k_compress_large<0>, 1: the first FFT trip's tiles are pending, 2: finished
+    uint32_t bitdepth, K1, big, Z;
+    uint32_t best_size;
+    int32_t best_owner;
+    uint32_t poly_final;  // the polynomial ladder ended with its first trip
+    uint32_t poly_size, poly_K, poly_step, poly2_lb, rle_lb;
+    uint32_t nlist;       // points in the bucketed list
+    double smin, smax, poly_err;
+    float mxf, mnf;
+};
 // What the first part of a split run hands to the second (PART 1 -> k_large_trip_tiles -> PART 2)
 struct TripState {
     double smin, smax, poly_err, pcur;
@@ -1216,6 +1228,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     const float2 *tw = twpool + P.tw_off;
     uint8_t *out = slots + fr.slot_off;
     int mode = prm.mode;
+    // behind the fast path (atsc_large_fast.h): only the frames it left undecided
+    if (PART == 0 && prm.fast_skip && ((const FastState *)(ws + lay.o_front))->status == 2) return;
 
     auto gpad = [&](uint32_t j) -> double {  // fft.rs:184-204
         int32_t i = (int32_t)j - (int32_t)pre;
@@ -2353,6 +2367,8 @@ __global__ __launch_bounds__(LT) void k_large_trip_tiles(
     if (tid == 0) ((double *)(Cb + TRIP_PARTIAL_OFF))[blockIdx.y] = s;
 }
 
+#include "atsc_large_fast.h"
+
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
@@ -2391,8 +2407,47 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         e = ensure_dyn_lds((const void *)k_large_pre23, lds2);
         if (e != hipSuccess) return e;
     }
+    // The fast path (atsc_large_fast.h): frames of 131072 samples under the auto selector, any number of them.
+    static const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;
+    const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p == 32 && pre->chunks_n && kp.sparse_inv &&
+                      kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
+                      (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
+    if (fast) {
+        e = ensure_dyn_lds((const void *)k_large_decide1, FAST_D1_LDS);
+        if (e != hipSuccess) return e;
+        e = ensure_dyn_lds((const void *)k_large_trip243, FAST_TILE_LDS);
+        if (e != hipSuccess) return e;
+        e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
+        if (e != hipSuccess) return e;
+        kp.prestats = 1;
+        kp.fast_skip = 1;
+    }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
+        if (fast) {
+            const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
+            hipLaunchKernelGGL(k_large_stats0, dim3(nb), dim3(64), 0, s, frames, ids + b0, plans, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_stats, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
+                               ws, ws_stride);
+            hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
+                               ws, ws_stride);
+            hipLaunchKernelGGL(k_large_cols243, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0, plans,
+                               twpool, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
+                               twpool, ws, ws_stride, (int)kp.sparse_inv);
+            hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), FAST_D1_LDS, s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, ws, ws_stride);
+            hipLaunchKernelGGL(k_large_trip243, dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s, samples, frames,
+                               ids + b0, plans, twpool, ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0);
+            hipLaunchKernelGGL(k_large_decide2, dim3(nb), dim3(LT), FAST_D2_LDS, s, samples, frames, ids + b0, plans, kp,
+                               slots, res, ws, ws_stride);
+            // whatever those left undecided (FastState::status != 2)
+            hipLaunchKernelGGL(k_compress_large<0>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, diag, ws, ws_stride);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            continue;
+        }
         if (split) {
             // statistics and first polynomial trip as (chunk, frame) grids; k_large_pre1 then resets the count of
             // zero bins only

@@ -1,0 +1,732 @@
+// atsc_large_fast.h -- included by atsc_large.hip (inside namespace atsc, after k_compress_large).
+//
+// Fast path of the large tier for frames whose transform splits as M = 243 x 288 (131072 samples, the frame the
+// reference chunker cuts long series into, optimizer/mod.rs:78-98) under the auto selector (frame/mod.rs:71-149).
+// k_compress_large runs a whole frame -- statistics, three candidates, every ladder trip, the payload -- in one
+// 1024-thread workgroup whose live state no register file holds (88-183 spilled VGPRs).  Most frames are decided by
+// the FIRST trip of each ladder: the polynomial's (k_large_poly1, a grid) and the FFT's, whose expensive part -- the
+// inverse transform and the error sum -- is a grid as well (k_large_trip243 below).  What is left per frame is two
+// short decision steps:
+//   k_large_decide1  statistics -> Constant shortcut; polynomial trip 1 (sums of k_large_poly1); RLE bound; if the
+//                    FFT's first payload can still win: the K1 = min(mf, Z) largest norms as a SET (histogram on the
+//                    norm's top 11 bits, collection, radix select among the candidates of the threshold digit -- no
+//                    sort: the trip's reconstruction does not depend on the order), the u16-wrap owners, the list of
+//                    packed-spectrum points bucketed by k mod 243
+//   k_large_trip243  (tile, frame) grid: 16 output columns per workgroup, direct sum over the buckets, 243-point
+//                    transforms in registers (as k_large_cols243), evaluation against the padded samples
+//   k_large_decide2  the trip's error, the selector, the payload (FFT: its bins sorted by norm now, once)
+// A frame these steps cannot finish (a ladder that needs a second trip and is not pruned, an RLE bound that could
+// still win, zero or NaN extremes, ...) is left untouched for k_compress_large<0>, launched behind them for the
+// frames not marked finished: every frame takes the same path whatever batch it arrives in.
+// Pruning is the selector's own arithmetic (a ladder's payload only grows, so a ladder stops once its next payload
+// cannot beat a candidate that already passes): the winner and its bytes are the reference's.
+
+constexpr uint32_t FAST_MF = 243, FAST_MD = 288, FAST_TILES = FAST_MD / 16;
+constexpr uint32_t FAST_CAND_MAX = 6144;   // candidates of the threshold digit held in LDS
+constexpr uint32_t FAST_K_MAX = 1344;      // K1 <= mf = n / 100 = 1310
+constexpr uint32_t FAST_OWN = 4608;        // positions below bins - 65536 = 4449 can collide after `pos as u16`
+constexpr uint32_t FAST_LIST_OFF = 0, FAST_BOUNDS_OFF = 65536, FAST_KEYS_OFF = 69632;  // inside buffer B
+constexpr uint32_t FAST_PARTIAL_OFF = 8192;  // inside buffer C (as TRIP_PARTIAL_OFF)
+
+DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t n, uint32_t bitdepth, uint32_t K,
+                         uint32_t step, double smin, double smax, double err, uint32_t *aux, uint32_t *wsum)
+{
+    // polynomial.rs:54-87 (as k_compress_large's emitter)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t hdr = 2 + vlen(K);
+    uint32_t body;
+    if (bitdepth == 0 || bitdepth == 3) {
+        const uint32_t vbytes = bitdepth == 0 ? 8u : 1u;
+        body = K * vbytes;
+        for (uint32_t k = tid; k < K; k += LT) {
+            const uint32_t t = (k == K - 1) ? (n - 1) : k * step;
+            put_value(out + hdr + k * vbytes, bitdepth, xs[t]);
+        }
+    } else {
+        for (uint32_t k = tid; k < K; k += LT) {
+            const uint32_t t = (k == K - 1) ? (n - 1) : k * step;
+            aux[k] = value_bytes(bitdepth, xs[t]);
+        }
+        __syncthreads();
+        body = block_excl_scan<LW>(aux, K, wsum);
+        for (uint32_t k = tid; k < K; k += LT) {
+            const uint32_t t = (k == K - 1) ? (n - 1) : k * step;
+            put_value(out + hdr + aux[k], bitdepth, xs[t]);
+        }
+    }
+    if (tid == 0) {
+        out[0] = 0;  // PolynomialType::Polynomial
+        out[1] = (uint8_t)bitdepth;
+        put_varint(out + 2, K);
+        put_f64(out + hdr + body, smin);
+        put_f64(out + hdr + body + 8, smax);
+        out[hdr + body + 16] = (uint8_t)step;
+        r.err = err;
+        r.len = hdr + body + 17;
+        r.chosen = ATSC_POLYNOMIAL;
+    }
+}
+
+__global__ __launch_bounds__(LT) void k_large_decide1(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
+    uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t fid = ids[blockIdx.x];
+    const DevFrame fr = frames[fid];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, L = P.L, bins = P.bins, M = P.M;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    const LargeWs lay = large_ws_layout(n, L, P.kcap);
+    FastState *fs = (FastState *)(ws + lay.o_front);
+    if (tid == 0) fs->status = 0;
+    // ATSC_DEBUG_STOP=-3: workgroup 0 prints the 100 MHz clock at its phase boundaries when it ends
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FSTAMP(i) do { if (prm.debug_stop <= -3) stamp[i] = wall_clock64(); } while (0)
+#define FSTAMP_PRINT(tag) do { if (prm.debug_stop <= -3 && (blockIdx.x == 0 || prm.debug_stop == -4) && tid == 0) \
+        printf("FSTAMP %s b%u %.1f %.1f %.1f %.1f %.1f %.1f %.1f\n", tag, blockIdx.x, (double)(stamp[1] - stamp[0]) * 0.01, \
+               (double)(stamp[2] - stamp[1]) * 0.01, (double)(stamp[3] - stamp[2]) * 0.01, (double)(stamp[4] - stamp[3]) * 0.01, \
+               (double)(stamp[5] - stamp[4]) * 0.01, (double)(stamp[6] - stamp[5]) * 0.01, (double)(stamp[7] - stamp[6]) * 0.01); } while (0)
+    FSTAMP(0);
+    if (P.f4_m1 != FAST_MF || P.f4_m2 != FAST_MD || !P.half || bins <= 65536 || bins - 65536 > FAST_OWN ||
+        P.mf > FAST_K_MAX)
+        return;
+    // LDS: [wsum 80][bc 64][red 256][h2 2048 u32][own FAST_OWN u64][above FAST_K_MAX u64][cand FAST_CAND_MAX u64]
+    uint32_t *wsum = (uint32_t *)smem;
+    uint32_t *bc = (uint32_t *)(smem + 128);
+    double *bcd = (double *)(smem + 192);
+    uint32_t *h2 = (uint32_t *)(smem + 512);
+    unsigned long long *own = (unsigned long long *)(smem + 512 + 8192);
+    unsigned long long *above = own + FAST_OWN;
+    unsigned long long *cand = above + FAST_K_MAX;
+    const double *xs = samples + fr.sample_off;
+    const float2 *tw = twpool + P.tw_off;
+    uint8_t *out = slots + fr.slot_off;
+
+    // ---- statistics (k_large_stats): optimizer/utils.rs:39-113 ----
+    const LargeStats *lst = (const LargeStats *)(ws + lay.o_cnt);
+    const double x0 = xs[0];
+    if (!(x0 == x0)) return;  // a NaN first sample keeps the scan's start value: left to the general kernel
+    const double smin = f64_unkey(lst->kmin), smax = f64_unkey(lst->kmax);
+    if (smin == 0.0 || smax == 0.0) return;  // the first zero of either sign has to be looked up
+    uint32_t bitdepth;
+    {
+        int64_t maxi, mini;
+        bool fz;
+        split_n(smax, maxi, fz);
+        split_n(smin, mini, fz);
+        bitdepth = lst->frac ? 0u : bitdepth_of(maxi, mini);
+    }
+    if (smin == smax) {  // frame/mod.rs:82-88
+        if (tid == 0) {
+            out[0] = 30;
+            out[1] = (uint8_t)bitdepth;
+            const uint32_t vb = put_value(out + 2, bitdepth, smin);
+            res[fid].err = 0.0;
+            res[fid].len = 2 + vb;
+            res[fid].chosen = ATSC_CONSTANT;
+            fs->status = 2;
+        }
+        return;
+    }
+    const double me = prm.max_err;
+    uint32_t best_size = 0xFFFFFFFFu;
+    int best_owner = 3;
+    auto can_win = [&](uint32_t size_lb, int owner) {
+        return size_lb < best_size || (size_lb == best_size && owner < best_owner);
+    };
+    auto offer = [&](uint32_t size, int owner) {
+        if (can_win(size, owner)) { best_size = size; best_owner = owner; }
+    };
+    // ---- RLE bound (rle.rs:142-189): run count and index bytes come with the statistics ----
+    const uint32_t rle_R = lst->runs, rle_ib = lst->ibytes;
+    const uint32_t rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * ((bitdepth == 0 ? 8u : 1u) + 1);
+
+    // ---- polynomial, first trip (polynomial.rs:209-277): the chunk sums of k_large_poly1, in chunk order ----
+    const uint32_t pstep = P.pstep[0], pK = P.pK[0];
+    if (!(pstep > 1 && pstep <= 256 && pK >= 2)) return;
+    if (tid == 0) {
+        double s = 0.0;
+        const double *part = (const double *)(ws + lay.o_part);
+        for (uint32_t c = 0; c < (n + LCH - 1) / LCH; ++c) s += part[c];
+        bcd[0] = s / (double)n;
+    }
+    uint32_t vb = 0;
+    if (bitdepth == 0 || bitdepth == 3) {
+        vb = pK * (bitdepth == 0 ? 8u : 1u);
+        __syncthreads();
+    } else {
+        for (uint32_t k = tid; k < pK; k += LT) vb += value_bytes(bitdepth, xs[(k == pK - 1) ? (n - 1) : k * pstep]);
+        int parity = 0;
+        vb = block_sum_u32<LW>(vb, (double *)(smem + 256), parity);  // (its barrier publishes bcd[0] too)
+    }
+    const double pcur = bcd[0];
+    const bool poly_final = !(round(pcur * 10000.0) > prm.poly_q_hi);  // polynomial.rs:231
+    const uint32_t poly_size = 2 + vlen(pK) + vb + 17;
+    const uint32_t poly2_lb = 2 + vlen(P.pK[1]) + P.pK[1] * (bitdepth == 0 ? 8u : 1u) + 17;
+    if (poly_final && pcur <= me) offer(poly_size, 1);
+
+    // ---- FFT (fft.rs:288-362) ----
+    const float mxf = (float)smax, mnf = (float)smin;
+    if (mxf == mnf) return;
+    const uint32_t Z = bins - lst->zeros;
+    const uint32_t K1 = min(P.mf, Z);
+    if (K1 < 8) return;
+    if (!can_win(1 + vlen(K1) + 9 * K1 + 8, 0)) {
+        // even the first trip's payload loses to the polynomial, which passes: no transform is evaluated at all
+        if (!(poly_final && pcur <= me) || can_win(rle_lb, 2)) return;
+        fast_emit_poly(out, res[fid], xs, n, bitdepth, pK, pstep, smin, smax, pcur, h2, wsum);
+        if (tid == 0) fs->status = 2;
+        return;
+    }
+
+    FSTAMP(1);  // 1: statistics, polynomial trip 1, bounds
+    // ---- the K1 largest norms (fft.rs:231-257), as a set ----
+    const uint32_t *nbits = (const uint32_t *)(ws + lay.o_nb);
+    for (uint32_t i = tid; i < 2048; i += LT) h2[i] = 0;
+    for (uint32_t i = tid; i < FAST_OWN; i += LT) own[i] = 0ull;
+    if (tid < 16) bc[tid] = 0;
+    if (tid == 0) bc[4] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t nq = bins >> 2;  // whole uint4 groups (the norm-bit region is 256-byte aligned)
+    constexpr uint32_t QPT = 6;     // groups in flight per thread
+    for (uint32_t q0 = 0; q0 < nq; q0 += QPT * LT) {
+        uint4 v[QPT];
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t q = q0 + u * LT + tid;
+            v[u] = q < nq ? ((const uint4 *)nbits)[q] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t q = q0 + u * LT + tid;
+            if (q < nq) {
+                atomicAdd(&h2[2047u - (v[u].x >> 20)], 1u);
+                atomicAdd(&h2[2047u - (v[u].y >> 20)], 1u);
+                atomicAdd(&h2[2047u - (v[u].z >> 20)], 1u);
+                atomicAdd(&h2[2047u - (v[u].w >> 20)], 1u);
+            }
+        }
+    }
+    for (uint32_t k = 4 * nq + tid; k < bins; k += LT) atomicAdd(&h2[2047u - (nbits[k] >> 20)], 1u);
+    __syncthreads();
+    FSTAMP(2);  // 2: histogram
+    {
+        const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
+        __syncthreads();
+        (void)block_excl_scan<LW>(h2, 2048, wsum);  // h2[i] = bins with a digit above 2047 - i
+        const uint32_t a0 = h2[2 * tid], a1 = h2[2 * tid + 1];
+        if (a0 < K1 && a0 + c0 >= K1) { bc[4] = 2 * tid; bc[5] = a0; bc[6] = c0; }
+        if (a1 < K1 && a1 + c1 >= K1) { bc[4] = 2 * tid + 1; bc[5] = a1; bc[6] = c1; }
+        __syncthreads();
+    }
+    if (bc[4] == 0xFFFFFFFFu) return;
+    const uint32_t dstar = 2047u - bc[4], n_above = bc[5], n_cand = bc[6];
+    if (n_cand > FAST_CAND_MAX) return;
+    {
+        const uint32_t lane = tid & 63u;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        auto visit = [&](uint32_t k, uint32_t v, bool in) {
+            const uint32_t d = v >> 20;
+            const bool ab = in && d > dstar, cd = in && d == dstar;
+            const unsigned long long key = ((unsigned long long)(~v) << 32) | (unsigned long long)k;
+            const uint64_t ma = __ballot(ab), mc = __ballot(cd);
+            if (ma) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&bc[2], (uint32_t)__popcll(ma));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (ab) above[base + (uint32_t)__popcll(ma & lt)] = key;
+            }
+            if (mc) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&bc[3], (uint32_t)__popcll(mc));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (cd) cand[base + (uint32_t)__popcll(mc & lt)] = key;
+            }
+        };
+        for (uint32_t q0 = 0; q0 < nq; q0 += QPT * LT) {
+            uint4 v[QPT];
+#pragma unroll
+            for (uint32_t u = 0; u < QPT; ++u) {
+                const uint32_t q = q0 + u * LT + tid;
+                v[u] = q < nq ? ((const uint4 *)nbits)[q] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < QPT; ++u) {
+                const uint32_t q = q0 + u * LT + tid;
+                const bool in = q < nq;
+                visit(4 * q, v[u].x, in);
+                visit(4 * q + 1, v[u].y, in);
+                visit(4 * q + 2, v[u].z, in);
+                visit(4 * q + 3, v[u].w, in);
+            }
+        }
+        for (uint32_t k0 = 4 * nq; k0 < bins; k0 += LT) {
+            const uint32_t k = k0 + tid;
+            visit(k, k < bins ? nbits[k] : 0u, k < bins);
+        }
+        __syncthreads();
+    }
+    FSTAMP(3);  // 3: digit, collection
+    // the `take` smallest candidate keys (norm descending, position ascending): radix select of the take-th smallest
+    // 37-bit key -- 20 norm bits below the digit, 17 position bits -- 11 bits a level
+    const uint32_t take = K1 - n_above;  // 1 .. n_cand
+    unsigned long long prefix = 0, resolved = 0;
+    {
+        uint32_t remaining = take;
+        auto k37 = [](unsigned long long key) -> unsigned long long {
+            return ((key >> 32) & 0xFFFFFull) << 17 | (key & 0x1FFFFull);
+        };
+        for (int shift = 26; shift >= -7; shift -= 11) {
+            const int sh = shift < 0 ? 0 : shift;
+            const uint32_t nb = shift < 0 ? 4u : 11u;  // the last level holds the 4 bits left
+            const uint32_t dm = (1u << nb) - 1u;
+            for (uint32_t i = tid; i < 2048; i += LT) h2[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n_cand; i += LT) {
+                const unsigned long long kk = k37(cand[i]);
+                if ((kk & resolved) == prefix) atomicAdd(&h2[(uint32_t)(kk >> sh) & dm], 1u);
+            }
+            __syncthreads();
+            const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
+            __syncthreads();
+            (void)block_excl_scan<LW>(h2, 2048, wsum);  // h2[i] = keys with a smaller digit
+            const uint32_t a0 = h2[2 * tid], a1 = h2[2 * tid + 1];
+            if (c0 && a0 < remaining && a0 + c0 >= remaining) { bc[8] = 2 * tid; bc[9] = a0; }
+            if (c1 && a1 < remaining && a1 + c1 >= remaining) { bc[8] = 2 * tid + 1; bc[9] = a1; }
+            __syncthreads();
+            prefix |= (unsigned long long)bc[8] << sh;
+            resolved |= (unsigned long long)dm << sh;
+            remaining -= bc[9];
+            __syncthreads();
+        }
+        // keys are distinct: exactly `take` candidates have k37 <= prefix
+    }
+    FSTAMP(4);  // 4: radix select
+    // ---- admission: sel[] (any order), sort keys for the payload, `pos as u16` owners, count of 3-byte positions ----
+    Sel *sel = (Sel *)(ws + lay.o_sel);
+    unsigned char *Bb = ws + lay.o_b;
+    unsigned long long *skey = (unsigned long long *)(Bb + FAST_KEYS_OFF);
+    const float2 *spec = (const float2 *)(ws + lay.o_a);
+    uint32_t big = 0;
+    if (tid == 0) bc[2] = n_above;  // next free slot behind the bins above the digit
+    __syncthreads();
+    {
+        auto k37 = [](unsigned long long key) -> unsigned long long {
+            return ((key >> 32) & 0xFFFFFull) << 17 | (key & 0x1FFFFull);
+        };
+        auto admit = [&](uint32_t i, unsigned long long key) {
+            const uint32_t pos = (uint32_t)(key & 0xffffffffull);
+            const float2 z = spec[pos];
+            sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
+            skey[i] = key;
+            const uint32_t p16 = pos & 0xffffu;
+            big += p16 >= 251 ? 1u : 0u;
+            if (p16 < FAST_OWN) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
+        };
+        for (uint32_t i = tid; i < n_above; i += LT) admit(i, above[i]);
+        for (uint32_t i = tid; i < n_cand; i += LT) {
+            const unsigned long long key = cand[i];
+            if (k37(key) <= prefix) admit(atomicAdd(&bc[2], 1u), key);
+        }
+    }
+    {
+        int parity = 0;
+        big = block_sum_u32<LW>(big, (double *)(smem + 256), parity);
+    }
+    __syncthreads();
+    if (bc[2] != K1) return;  // (cannot happen: the select is exact)
+    FSTAMP(5);  // 5: admission
+    // ---- the trip's packed-spectrum points, bucketed by k mod 243 (see sparse_bucket) ----
+    // (the candidate list is done with: its LDS hosts the list)
+    SpEnt *zl = (SpEnt *)cand;                       // <= 2 K1 points of 12 bytes
+    uint32_t *beg = h2, *end = h2 + 256, *cnt = h2 + 512;
+    for (uint32_t e = tid; e < 256; e += LT) { beg[e] = 0; cnt[e] = 0; }
+    __syncthreads();
+    auto points = [&](uint32_t i, uint32_t (&kk)[2], float2 (&vv)[2]) -> uint32_t {
+        const Sel e = sel[i];
+        const uint32_t p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
+        if (p < FAST_OWN && own[p] != skey[i]) return 0;
+        const float2 x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
+        // (p <= 65535 < M for this class: the first point always exists; it takes slot 0, the mirror slot 1)
+        {
+            const float2 h = make_float2(0.5f * x.x, 0.5f * x.y);
+            const float2 o = cmulp(h, tw[p]);
+            kk[0] = p;
+            vv[0] = make_float2(h.x - o.y, -(h.y + o.x));
+        }
+        if (p >= 1) {
+            const float2 ee = make_float2(0.5f * x.x, -0.5f * x.y);
+            const float2 d = make_float2(-0.5f * x.x, 0.5f * x.y);
+            const float2 o = cmulp(d, tw[M - p]);
+            kk[1] = (M - p) | 0x80000000u;
+            vv[1] = make_float2(ee.x - o.y, -(ee.y + o.x));
+            return 2;
+        }
+        return 1;
+    };
+    uint32_t mykk[2][2];
+    float2 myvv[2][2];
+    uint32_t myc[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // K1 <= FAST_K_MAX <= 2 LT
+        const uint32_t i = tid + u * LT;
+        if (i < K1) {
+            myc[u] = points(i, mykk[u], myvv[u]);
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                if (q < myc[u]) atomicAdd(&beg[(mykk[u][q] & 0x7fffffffu) % FAST_MF], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 243 bucket sizes by one wavefront (4 per lane)
+        uint32_t c[4], s = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = beg[4 * tid + u]; s += c[u]; }
+        const uint32_t incl = wave_incl_scan_u32(s);
+        uint32_t run = incl - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { beg[4 * tid + u] = run; run += c[u]; }
+        if (tid == 63) bc[10] = incl;
+    }
+    __syncthreads();
+    const uint32_t nlist = bc[10];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            if (q >= myc[u]) continue;
+            const uint32_t k = mykk[u][q] & 0x7fffffffu;
+            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
+            const uint32_t slot = beg[ka] + atomicAdd(&cnt[ka], 1u);
+            SpEnt z;
+            z.key = (kb << 1) | (mykk[u][q] >> 31);
+            z.re = myvv[u][q].x;
+            z.im = myvv[u][q].y;
+            zl[slot] = z;
+        }
+    __syncthreads();
+    // Every bucket in ascending (kb, kind) order -- the f32 sums of the tiles do not depend on the order the atomics
+    // happened to serve -- by counting: an entry's place is the number of smaller keys in its bucket (keys are
+    // distinct), one thread per entry.  (An insertion sort by one thread per bucket took 70 us on frames whose bins sit
+    // on few residues: a signal of period 64 puts every harmonic on a multiple of L / 64 = 9 * 243.)
+    SpEnt *zs = (SpEnt *)own;  // the owners are done with (points() ran): 32 KB of their 36 KB
+    if (tid < FAST_MF) end[tid] = beg[tid] + cnt[tid];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            if (q >= myc[u]) continue;
+            const uint32_t k = mykk[u][q] & 0x7fffffffu;
+            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
+            const uint32_t key = (kb << 1) | (mykk[u][q] >> 31);
+            const uint32_t b = beg[ka], e = end[ka];
+            uint32_t rank = 0;
+            for (uint32_t t = b; t < e; ++t) rank += zl[t].key < key ? 1u : 0u;
+            SpEnt z;
+            z.key = key;
+            z.re = myvv[u][q].x;
+            z.im = myvv[u][q].y;
+            zs[b + rank] = z;
+        }
+    // the buckets by descending size (ties by index): the tiles deal them over their thread groups in this order
+    uint32_t *border = cnt + 256;  // h2[768 ..]
+    if (tid < FAST_MF) {
+        const uint32_t mine = cnt[tid];
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < FAST_MF; ++t) {
+            const uint32_t o = cnt[t];
+            rank += (o > mine || (o == mine && t < tid)) ? 1u : 0u;
+        }
+        border[rank] = tid;
+    }
+    __syncthreads();
+    FSTAMP(6);  // 6: bucketing
+    {
+        uint32_t *gl = (uint32_t *)(Bb + FAST_LIST_OFF);
+        const uint32_t *src = (const uint32_t *)zs;
+        for (uint32_t w = tid; w < 3 * nlist; w += LT) gl[w] = src[w];
+        uint32_t *gb = (uint32_t *)(Bb + FAST_BOUNDS_OFF);
+        for (uint32_t e = tid; e < FAST_MF; e += LT) { gb[e] = beg[e]; gb[256 + e] = end[e]; gb[512 + e] = border[e]; }
+    }
+    if (tid == 0) {
+        FastState f;
+        f.status = 1;
+        f.bitdepth = bitdepth; f.K1 = K1; f.big = big; f.Z = Z;
+        f.best_size = best_size; f.best_owner = best_owner;
+        f.poly_final = poly_final ? 1u : 0u;
+        f.poly_size = poly_size; f.poly_K = pK; f.poly_step = pstep; f.poly2_lb = poly2_lb; f.rle_lb = rle_lb;
+        f.nlist = nlist;
+        f.smin = smin; f.smax = smax; f.poly_err = pcur;
+        f.mxf = mxf; f.mnf = mnf;
+        *fs = f;
+    }
+    FSTAMP(7);  // 7: list and state out
+    FSTAMP_PRINT("decide1");
+}
+
+// One tile (16 output columns jb) of the first FFT trip of one frame: F[288 ja + jb] for every ja, compared with the
+// padded samples 2 j, 2 j + 1 (j = 288 ja + jb); the tile's share of the MAPE sum goes to buffer C.
+// Thread (column c, q): inputs ka = 9 a + q of its column straight from the buckets, then as k_large_cols243.
+__global__ __launch_bounds__(CT) void k_large_trip243(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base,
+    uint64_t ws_stride, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
+#define TSTAMP(i) do { if (dbg) tstamp[i] = wall_clock64(); } while (0)
+    TSTAMP(0);
+    const DevFrame fr = frames[ids[blockIdx.y]];
+    const DevPlan &P = plans[fr.plan];
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
+    const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
+    const FastState *fs = (const FastState *)(ws + lay.o_front);
+    if (fs->status != 1) return;
+    const uint32_t n = P.n, L = P.L, pre = P.pre;
+    const float2 *tw = twpool + P.tw_off;
+    const double *xs = samples + fr.sample_off;
+    // LDS: [T 243 x 17 points][w1 243][wd 288][beg 256][end 256][list]
+    float2 *T = (float2 *)smem;
+    float2 *w1 = T + 243 * CSI;
+    float2 *wd = w1 + 243;
+    uint32_t *beg = (uint32_t *)(wd + FAST_MD), *end = beg + 256, *border = end + 256;
+    const unsigned char *Bb = ws + lay.o_b;
+    const SpEnt *gl = (const SpEnt *)(Bb + FAST_LIST_OFF);  // the list stays in memory (L2: the frame's 18 tiles share it)
+    const uint32_t nlist = fs->nlist;
+    {
+        const uint32_t *gb = (const uint32_t *)(Bb + FAST_BOUNDS_OFF);
+        for (uint32_t e = tid; e < 256; e += CT) { beg[e] = gb[e]; end[e] = gb[256 + e]; border[e] = gb[512 + e]; }
+        for (uint32_t e = tid; e < 243; e += CT) w1[e] = tw[e * (L / FAST_MF)];
+        for (uint32_t e = tid; e < FAST_MD; e += CT) wd[e] = tw[e * (L / FAST_MD)];
+    }
+    const uint32_t c = tid & 15u, q = tid >> 4;
+    const uint32_t jb = blockIdx.x * 16 + c;
+    const bool live = q < 9;
+    __syncthreads();
+    TSTAMP(1);
+    // Inputs of the column transforms: T[ka][c] = G[ka][jb] times W_M^{jb ka} (jb ka < M: no wrap).  The twelve groups
+    // of 16 lanes (one DPP row each) take the buckets in the order of their size (largest first, round-robin): bins
+    // that sit on few residues mod 243 would otherwise leave one group summing while the others wait.  A group reads
+    // its bucket 16 entries at a time, one per lane, straight from memory (the next batch is requested before the
+    // current one is used) and hands entry u to its 16 columns by a row broadcast: the list never sits in LDS, which
+    // is what lets four of these workgroups share a CU.  The sum over a bucket runs in list order whichever group it
+    // falls to (slots past the bucket's end add zeros).
+    {
+        const uint32_t grp = tid >> 4;  // 0 .. 11
+        auto mod288 = [](uint32_t x) -> uint32_t {  // x < 288 * 288
+            const uint32_t t = x >> 5, qq = (t * 7282u) >> 16;
+            return ((t - 9u * qq) << 5) | (x & 31u);
+        };
+        auto fetch = [&](uint32_t e, uint32_t e1) -> SpEnt {
+            SpEnt z;
+            z.key = 0; z.re = 0.0f; z.im = 0.0f;
+            if (e + c < e1) z = gl[e + c];
+            return z;
+        };
+        uint32_t i = grp;
+        uint32_t ka = border[i], e = beg[ka], e1 = end[ka];
+        SpEnt nxt = fetch(e, e1);
+        float2 twn = tw[jb * ka * P.sc];
+        float2 acc = make_float2(0.0f, 0.0f);
+        while (i < FAST_MF) {
+            const SpEnt cur = nxt;
+            const float2 twc = twn;
+            const uint32_t kc = ka;
+            const uint32_t cnt = min(16u, e1 - e);
+            const bool last = e + 16 >= e1;
+            // where the next batch comes from
+            uint32_t ni = i;
+            if (last) {
+                ni = i + CT / 16;
+                if (ni < FAST_MF) { ka = border[ni]; e = beg[ka]; e1 = end[ka]; twn = tw[jb * ka * P.sc]; }
+            } else {
+                e += 16;
+            }
+            if (ni < FAST_MF) nxt = fetch(e, e1);
+            // (slot U is run while any active row of the wavefront still has an entry there: a uniform branch)
+#define ATSC_BKT(U)                                                                                          \
+            if (__ballot(U < cnt)) {                                                                              \
+                const uint32_t ku = dpp_u32<0x150 + U, 0xf>(cur.key);                                             \
+                const float ru = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.re)));                \
+                const float iu = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.im)));                \
+                const float2 t = cmulc(make_float2(ru, iu), wd[mod288(jb * (ku >> 1))]);                          \
+                acc.x += t.x;                                                                                     \
+                acc.y += t.y;                                                                                     \
+            }
+            ATSC_BKT(0) ATSC_BKT(1) ATSC_BKT(2) ATSC_BKT(3) ATSC_BKT(4) ATSC_BKT(5) ATSC_BKT(6) ATSC_BKT(7)
+            ATSC_BKT(8) ATSC_BKT(9) ATSC_BKT(10) ATSC_BKT(11) ATSC_BKT(12) ATSC_BKT(13) ATSC_BKT(14) ATSC_BKT(15)
+#undef ATSC_BKT
+            if (last) {
+                T[kc * CSI + c] = cmulc(acc, twc);
+                acc = make_float2(0.0f, 0.0f);
+            }
+            i = ni;
+        }
+    }
+    __syncthreads();
+    TSTAMP(2);
+    float2 a[27];
+#pragma unroll
+    for (int aa = 0; aa < 27; ++aa) a[aa] = live ? T[(9u * aa + q) * CSI + c] : make_float2(0.0f, 0.0f);
+    __syncthreads();  // every thread holds its inputs: T becomes the exchange buffer
+    dft27f(a);
+    if (live) {
+#pragma unroll
+        for (int ka = 1; ka < 27; ++ka) a[ka] = cmulc(a[ka], w1[q * ka]);
+#pragma unroll
+        for (int ka = 0; ka < 27; ++ka) T[(q * 27 + ka) * CSI + c] = a[ka];
+    }
+    __syncthreads();
+    TSTAMP(3);
+    // Evaluation: ja = (q + 9 m) + 27 kq, samples 2 j and 2 j + 1, j = 288 ja + jb, against the padded signal (pre and n
+    // are even for this class: a pair never straddles a frame edge).  The samples of group m + 1 are requested while
+    // group m is transformed and evaluated.
+    double s = 0.0;
+    if (live) {
+        const double mxd = (double)fs->mxf, mnd = (double)fs->mnf;
+        const float Lf = (float)L;
+        auto term = [&](float re, double gg) {  // fft.rs:341-345, utils/error.rs:104-116
+            const double v = (double)(re / Lf);
+            double o = div1e5(round(v * 100000.0));
+            if (o > mxd) o = mxd;
+            if (o < mnd) o = mnd;
+            s += fabs(o - gg) * recip_abs(gg);
+        };
+        auto gload = [&](uint32_t m, double2 (&g)[9]) {
+#pragma unroll
+            for (int kq = 0; kq < 9; ++kq) {
+                const uint32_t ja = (q + 9u * m) + 27u * kq;
+                const int32_t j2 = (int32_t)(2 * (FAST_MD * ja + jb)) - (int32_t)pre;
+                const int32_t jc = j2 < 0 ? 0 : (j2 >= (int32_t)n ? (int32_t)n - 2 : j2);
+                double2 v = *(const double2 *)(xs + jc);
+                if (j2 < 0) v.y = v.x;
+                if (j2 >= (int32_t)n) v.x = v.y;
+                g[kq] = v;
+            }
+        };
+        double2 gn[9];
+        gload(0, gn);
+#pragma unroll 1
+        for (uint32_t m = 0; m < 3; ++m) {
+            double2 g[9];
+#pragma unroll
+            for (int kq = 0; kq < 9; ++kq) g[kq] = gn[kq];
+            if (m + 1 < 3) gload(m + 1, gn);
+            const uint32_t ka = q + 9u * m;
+            float2 b[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) b[j] = T[(j * 27 + ka) * CSI + c];
+            dft9f(b);
+#pragma unroll
+            for (int kq = 0; kq < 9; ++kq) {  // idft_L = 2 idft_M: even sample -> re, odd sample -> -im
+                term(2.0f * b[kq].x, g[kq].x);
+                term(-2.0f * b[kq].y, g[kq].y);
+            }
+        }
+    }
+    // block sum in a fixed order: wavefront DPP trees, then the three wavefronts in turn
+    double *red = (double *)T;
+    __syncthreads();
+    const double wsum_ = wave_sum_f64(s);
+    if ((tid & 63) == 0) red[tid >> 6] = wsum_;
+    __syncthreads();
+    if (tid == 0) ((double *)(ws + lay.o_c + FAST_PARTIAL_OFF))[blockIdx.x] = (red[0] + red[1]) + red[2];
+    TSTAMP(4);
+    if (dbg && tid == 0 && blockIdx.x == 3 && blockIdx.y < 5)
+        printf("TSTAMP trip243 frame %u: setup %.1f  bucket sums %.1f  column transform %.1f  evaluation %.1f us (nlist %u)\n", blockIdx.y,
+               (double)(tstamp[1] - tstamp[0]) * 0.01, (double)(tstamp[2] - tstamp[1]) * 0.01,
+               (double)(tstamp[3] - tstamp[2]) * 0.01, (double)(tstamp[4] - tstamp[3]) * 0.01, nlist);
+}
+
+// The decision after the first FFT trip: frame/mod.rs:113-147 with every ladder either ended or pruned; anything
+// else leaves the frame to k_compress_large<0>.
+__global__ __launch_bounds__(LT) void k_large_decide2(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const KParams prm, uint8_t *__restrict__ slots, DevResult *__restrict__ res,
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t fid = ids[blockIdx.x];
+    const DevFrame fr = frames[fid];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t n = P.n, L = P.L;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    const LargeWs lay = large_ws_layout(n, L, P.kcap);
+    FastState *fs = (FastState *)(ws + lay.o_front);
+    if (fs->status != 1) return;
+    const FastState f = *fs;
+    __syncthreads();
+    uint32_t *wsum = (uint32_t *)smem;
+    uint32_t *aux = (uint32_t *)(smem + 512);                       // 2048 u32
+    unsigned long long *keys = (unsigned long long *)(smem + 512 + 8192);  // 2048 u64
+    uint32_t *pay = (uint32_t *)(keys + 2048);                       // 2048 u32
+    const double *xs = samples + fr.sample_off;
+    uint8_t *out = slots + fr.slot_off;
+    const double me = prm.max_err;
+    double s = 0.0;
+    {
+        const double *part = (const double *)(ws + lay.o_c + FAST_PARTIAL_OFF);
+        for (uint32_t t = 0; t < FAST_TILES; ++t) s += part[t];
+    }
+    const double cur = s / (double)L;  // mean over the padded samples (fft.rs:345)
+    uint32_t best_size = f.best_size;
+    int best_owner = f.best_owner;
+    auto can_win = [&](uint32_t size_lb, int owner) {
+        return size_lb < best_size || (size_lb == best_size && owner < best_owner);
+    };
+    const uint32_t K1 = f.K1;
+    const uint32_t fft_size = 1 + vlen(K1) + 9 * K1 + 2 * f.big + 8;
+    const bool fft_ends = !(prm.max_err_m < sat_i32(cur * 1000.0));  // fft.rs:334
+    if (fft_ends) {
+        if (cur <= me && can_win(fft_size, 0)) { best_size = fft_size; best_owner = 0; }
+    } else {
+        // the ladder goes on with K2 bins: pruned only if that payload cannot beat a candidate that passes
+        const uint32_t K2 = min(P.mf + P.dk1, f.Z);
+        if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) fs->status = 0; return; }
+    }
+    if (!f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; return; }
+    if (can_win(f.rle_lb, 2) || best_owner == 3) { if (tid == 0) fs->status = 0; return; }
+    if (best_owner == 1) {
+        fast_emit_poly(out, res[fid], xs, n, f.bitdepth, f.poly_K, f.poly_step, f.smin, f.smax, f.poly_err, aux, wsum);
+    } else {
+        // FFT payload (fft.rs:119-130): the bins by descending norm, equal norms by position (the large tier's order)
+        const Sel *sel = (const Sel *)(ws + lay.o_sel);
+        const unsigned long long *skey = (const unsigned long long *)(ws + lay.o_b + FAST_KEYS_OFF);
+        for (uint32_t i = tid; i < K1; i += LT) { keys[i] = skey[i]; pay[i] = i; }
+        __syncthreads();
+        uint32_t p2 = 1;
+        while (p2 < K1) p2 <<= 1;
+        block_sort<LW, false>((uint64_t *)keys, pay, K1, p2);
+        const uint32_t hdr = 1 + vlen(K1);
+        for (uint32_t i = tid; i < K1; i += LT) aux[i] = vlen(sel[pay[i]].pos & 0xffffu) + 8;
+        __syncthreads();
+        const uint32_t body = block_excl_scan<LW>(aux, K1, wsum);
+        for (uint32_t i = tid; i < K1; i += LT) {
+            const Sel e = sel[pay[i]];
+            uint8_t *p = out + hdr + aux[i];
+            p += put_varint(p, e.pos & 0xffffu);
+            put_f32(p, e.re);
+            put_f32(p + 4, e.im);
+        }
+        if (tid == 0) {
+            out[0] = 15;
+            put_varint(out + 1, K1);
+            put_f32(out + hdr + body, f.mxf);
+            put_f32(out + hdr + body + 4, f.mnf);
+            res[fid].err = cur;
+            res[fid].len = hdr + body + 8;
+            res[fid].chosen = ATSC_FFT;
+        }
+    }
+    if (tid == 0) fs->status = 2;
+}
+
+constexpr uint32_t FAST_D1_LDS = 512 + 8192 + 8 * (FAST_OWN + FAST_K_MAX + FAST_CAND_MAX);
+constexpr uint32_t FAST_TILE_LDS = 8 * (243 * CSI + 243 + FAST_MD) + 4 * 768;
+constexpr uint32_t FAST_D2_LDS = 512 + 8192 + 8 * 2048 + 4 * 2048;
