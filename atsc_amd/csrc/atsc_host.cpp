@@ -149,7 +149,7 @@ struct atsc_plan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;        // form of the large tier's in-kernel transforms
-    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched pre-pass of the large tier (tiles1 == 0: off)
     // atsc_compress_plan_dev_pipelined: consecutive calls go round-robin over up to four chains.  A chain is a stream
     // of the context's (atsc_ctx::chain_streams) plus everything a batch in flight owns: scratch set (payload slots,
     // results, scan scratch), large-tier workspace, cost records and the launch order derived from them.  Chain 0's
@@ -194,7 +194,7 @@ struct atsc_dplan {
     uint64_t ws_stride = 0;
     uint32_t ws_slots = 0;
     bool large_tiled = false;
-    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
+    LargePre large_pre{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // batched inverse transform of the large FFT frames (tiles1 == 0: off)
     uint32_t large_sp_tiles = 0;        // tiles per frame of the sparse inverse's (tile, frame) grid (0: off)
 };
 
@@ -308,13 +308,13 @@ static bool large_sparse() { return getenv("ATSC_LARGE_DENSE") == nullptr; }
 // the whole GPU before the per-frame kernel); all zero when a large frame length has no M1 x M2 split.
 static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
 {
-    LargePre pre{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LargePre pre{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool first_large = true;
     if (getenv("ATSC_LARGE_NO_PREPASS")) return pre;
     pre.cols243 = getenv("ATSC_LARGE_OLD_COLS") ? 0u : 1u;
     for (uint32_t pi : large_plan_ids) {
         const DevPlan &p = plans[pi];
-        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!p.f4_m1) return LargePre{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         pre.tiles1 = std::max(pre.tiles1, (p.f4_m2 + 15) / 16);
         pre.tiles2 = std::max(pre.tiles2, (p.f4_m1 + 15) / 16);
         pre.chunks = std::max(pre.chunks, (p.bins + 255) / 256);
@@ -774,6 +774,9 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
         std::sort(lp.begin(), lp.end());
         lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
         p->large_pre = large_pre_extents(p->tabs.plans, lp);
+        p->large_pre.even_off = 1;
+        for (uint64_t f = 0; f < n_frames; ++f)
+            if (cls[f] == CLASS_LARGE && (frames[f].sample_off & 1ull)) p->large_pre.even_off = 0;
     }
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_plan_destroy(p); return rc; }
@@ -1088,6 +1091,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.prefft = 0;
     prm.prestats = 0;
     prm.fast_skip = 0;
+    prm.tile_stats = 0;
     unsigned char *ws_set = pipelined ? CH.d_ws : plan->d_ws;  // large-tier workspace of this call
     if (pipelined && ((compressor == ATSC_AUTO && sample_level > 0) || (compressor == ATSC_FFT && !bounded))) {
         // the sub-plans below (trial prefixes, unpadded transforms) keep one result / table set per plan: such calls

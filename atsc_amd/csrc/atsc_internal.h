@@ -122,6 +122,7 @@ struct KParams {
     uint32_t sparse_inv;         // large tier: per-trip inverse transform from the sparse bin list
     uint32_t prestats;           // large tier, split run: the statistics (LargeStats) and the chunk sums of the first
                                  // polynomial trip are in the frame's workspace slot (k_large_stats, k_large_poly1)
+    uint32_t tile_stats;         // large tier, fast path: the frame statistics are the column tiles' records (TileStats)
     uint32_t fast_skip;          // large tier: k_compress_large<0> runs behind the fast path and skips the frames that
                                  // path finished (FastState::status == 2)
     uint32_t prefft;             // large tier: forward transform, untangle and norms were done by the
@@ -136,6 +137,7 @@ struct LargePre {
     uint32_t chunks_n;                // most 4096-sample chunks a frame has (k_large_stats, k_large_poly1)
     uint32_t cols243;                 // 1: every large frame length splits as M = 243 x M2 (k_large_cols243)
     uint32_t rows9p;                  // P when every large frame length has M2 = 9 P, P = 32 (k_large_rows9p), else 0
+    uint32_t even_off;                // 1: every large frame starts on an even sample (16-byte pairs, given an aligned base)
 };
 constexpr uint32_t LARGE_SPLIT_MAX = 128;  // large frames per launch up to which the first FFT trip's tiles
                                            // run as a (tile, frame) grid (launch_compress_large)

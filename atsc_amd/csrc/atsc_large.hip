@@ -339,7 +339,7 @@ DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw,
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, o_part, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, o_part, o_tst, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -362,7 +362,9 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_spos = o; o += lw_align(4ull * (16384 + 8));  // admission order (bin positions) once sorted: frees the LDS
     w.o_cnt = o; o += lw_align(16);                   // pre-pass: number of ZERO bins (rare: few atomics)
     w.o_front = o; o += lw_align(256);                // k_compress_large<1> -> <2>: TripState
-    w.o_part = o; o += lw_align(8 * 64);              // k_large_poly1: MAPE sums of the chunks of the first polynomial trip
+    w.o_part = o; o += lw_align(4096);                // first polynomial trip: MAPE sums of the 4096-sample chunks (k_large_poly1);
+                                                      // fast path: [512] sums and [1536] run counts of the 1024-sample pieces
+    w.o_tst = o; o += lw_align(32 * 32);              // k_large_cols243: statistics of each column tile (TileStats)
     w.bytes = o;
     return w;
 }
@@ -939,7 +941,13 @@ __global__ __launch_bounds__(PT) void k_large_pre23(const double *__restrict__ s
         if ((threadIdx.x & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
     }
 }
-#include "atsc_large_cols.h"
+// Statistics of one column tile of the forward transform's first pass (k_large_cols243 sees every sample of the frame
+// exactly once): plain stores, one record per tile, combined by the readers -- no atomics, nothing to initialise.
+struct TileStats {
+    double mn, mx;            // +inf / -inf when the tile saw no comparable sample
+    uint32_t frac, runs, ibytes, pad;
+};
+constexpr uint32_t TST_MAX = 32;  // records per frame (M2 / 16 tiles; 18 for 131072 samples)
 
 // --------------------------------------------------------------------------------------------
 // k_compress_large
@@ -965,6 +973,35 @@ DEVI double f64_unkey(unsigned long long k)
 {
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
 }
+// The frame statistics, from k_large_stats' record or from the column tiles' records (k_large_cols243<true>)
+struct FrameStats {
+    double mn, mx;
+    uint32_t frac, runs, ibytes;
+};
+DEVI FrameStats frame_stats(const unsigned char *ws, const LargeWs &lay, bool tiles, uint32_t ntiles, uint32_t nchunks = 0)
+{
+    FrameStats r;
+    if (!tiles) {
+        const LargeStats *lst = (const LargeStats *)(ws + lay.o_cnt);
+        r.mn = f64_unkey(lst->kmin); r.mx = f64_unkey(lst->kmax);
+        r.frac = lst->frac; r.runs = lst->runs; r.ibytes = lst->ibytes;
+        return r;
+    }
+    const TileStats *t = (const TileStats *)(ws + lay.o_tst);
+    r.mn = __longlong_as_double(0x7ff0000000000000ll); r.mx = -r.mn;
+    r.frac = r.runs = r.ibytes = 0;
+    for (uint32_t i = 0; i < ntiles; ++i) {
+        const TileStats q = t[i];
+        if (q.mn < r.mn) r.mn = q.mn;
+        if (q.mx > r.mx) r.mx = q.mx;
+        r.frac |= q.frac;
+    }
+    const uint2 *pc = (const uint2 *)(ws + lay.o_part + 1536);  // the polynomial chunks' run counts (0: the caller has no use for them)
+    for (uint32_t i = 0; i < nchunks; ++i) { r.runs += pc[i].x; r.ibytes += pc[i].y; }
+    return r;
+}
+#include "atsc_large_cols.h"
+
 __global__ void k_large_stats0(const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
                                const DevPlan *__restrict__ plans, unsigned char *__restrict__ ws_base,
                                uint64_t ws_stride)
@@ -1049,7 +1086,8 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
                                                     const DevFrame *__restrict__ frames,
                                                     const uint32_t *__restrict__ ids,
                                                     const DevPlan *__restrict__ plans,
-                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+                                                    unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+                                                    int tile_stats)
 {
     __shared__ double4 hbt[256];
     __shared__ double2 mms[LCH / 2 + 4];
@@ -1064,8 +1102,8 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
     if (step <= 1 || step > 256 || K < 2) return;
     unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
     const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
-    const LargeStats *st = (const LargeStats *)(ws + lay.o_cnt);
-    const double smin = f64_unkey(st->kmin), smax = f64_unkey(st->kmax);
+    const FrameStats st = frame_stats(ws, lay, tile_stats != 0, (P.f4_m2 + FB - 1) / FB);
+    const double smin = st.mn, smax = st.mx;
     const double *xs = samples + fr.sample_off;
     const uint32_t magic = P.pmagic[0];
     const uint32_t gapL = (n - 1) - (K - 2) * step;
@@ -1105,11 +1143,11 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
     }
     __syncthreads();
     double s = 0.0;
-    double g[LCH / LT], v0[LCH / LT], v1[LCH / LT];
+    double g[LCH / LT], v0[LCH / LT], v1[LCH / LT], pv[LCH / LT];
 #pragma unroll
     for (uint32_t u = 0; u < LCH / LT; ++u) {
         const uint32_t i = c0 + u * LT + tid;
-        g[u] = v0[u] = v1[u] = 0.0;
+        g[u] = v0[u] = v1[u] = pv[u] = 0.0;
         if (i < c1) {
             uint32_t sg = __umulhi(i, magic);
             if (sg > K - 2) sg = K - 2;
@@ -1117,6 +1155,15 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
             g[u] = xs[i];
             v0[u] = xs[t0i];
             v1[u] = xs[(sg == K - 2) ? (n - 1) : t0i + step];
+            if (tile_stats && i) pv[u] = xs[i - 1];
+        }
+    }
+    uint32_t runs = 0, ib = 0;  // rle.rs:142-189 run starts and their index bytes (as k_large_stats counts them)
+    if (tile_stats) {
+#pragma unroll
+        for (uint32_t u = 0; u < LCH / LT; ++u) {
+            const uint32_t i = c0 + u * LT + tid;
+            if (i < c1 && (i == 0 || g[u] != pv[u])) { ++runs; ib += vlen(i); }
         }
     }
 #pragma unroll
@@ -1148,6 +1195,11 @@ __global__ __launch_bounds__(LT) void k_large_poly1(const double *__restrict__ s
     int parity = 0;
     s = block_sum_f64<LW>(s, red, parity);
     if (tid == 0) ((double *)(ws + lay.o_part))[blockIdx.x] = s;
+    if (tile_stats) {  // the chunk's run statistics behind the 32 chunk sums (plain stores: the reader adds them up)
+        runs = block_sum_u32<LW>(runs, red, parity);
+        ib = block_sum_u32<LW>(ib, red, parity);
+        if (tid == 0 && blockIdx.x < 32) ((uint2 *)(ws + lay.o_part + 256))[blockIdx.x] = make_uint2(runs, ib);
+    }
 }
 
 // State of the fast path (atsc_large_fast.h)
@@ -2426,15 +2478,28 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         const uint32_t nb = min(ws_slots, count - b0);
         if (fast) {
             const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
-            hipLaunchKernelGGL(k_large_stats0, dim3(nb), dim3(64), 0, s, frames, ids + b0, plans, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_stats, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
-                               ws, ws_stride);
-            hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
-                               ws, ws_stride);
-            hipLaunchKernelGGL(k_large_cols243, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0, plans,
-                               twpool, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
-                               twpool, ws, ws_stride, (int)kp.sparse_inv);
+            // the statistics ride on the column pass when every frame can be read as aligned pairs
+            const bool tst = pre->even_off && (((uintptr_t)samples & 15u) == 0) && pre->tiles1 <= TST_MAX;
+            if (tst) {
+                hipLaunchKernelGGL(k_large_cols243<true>, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0,
+                                   plans, twpool, ws, ws_stride);
+            } else {
+                hipLaunchKernelGGL(k_large_stats0, dim3(nb), dim3(64), 0, s, frames, ids + b0, plans, ws, ws_stride);
+                hipLaunchKernelGGL(k_large_stats, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
+                                   ws, ws_stride);
+                hipLaunchKernelGGL(k_large_cols243<false>, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0,
+                                   plans, twpool, ws, ws_stride);
+            }
+            kp.tile_stats = tst ? 1u : 0u;
+            if (tst) {  // the row pass and the first polynomial trip's pieces in one launch
+                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23 + pre->chunks_n * (LCH / PCH), nb), dim3(RT), 0, s, samples,
+                                   frames, ids + b0, plans, twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
+            } else {
+                hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
+                                   ws, ws_stride, 0);
+                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
+                                   twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
+            }
             hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), FAST_D1_LDS, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, ws, ws_stride);
             hipLaunchKernelGGL(k_large_trip243, dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s, samples, frames,
@@ -2456,19 +2521,19 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                                ws, ws_stride);
             if (kp.mode == ATSC_AUTO)
                 hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0,
-                                   plans, ws, ws_stride);
+                                   plans, ws, ws_stride, 0);
         }
         if (kp.prefft) {
             if (pre->cols243)
-                hipLaunchKernelGGL(k_large_cols243, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0, plans,
-                                   twpool, ws, ws_stride);
+                hipLaunchKernelGGL(k_large_cols243<false>, dim3(pre->tiles1, nb), dim3(CT), 0, s, samples, frames, ids + b0,
+                                   plans, twpool, ws, ws_stride);
             else
                 hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples,
                                    frames, ids + b0, plans, twpool, ws, ws_stride);
             const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
             if (pre->cols243 && pre->rows9p == 32)
                 hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
-                                   twpool, ws, ws_stride, (int)kp.sparse_inv);
+                                   twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
             else
                 hipLaunchKernelGGL(k_large_pre23, dim3(tiles23, nb), dim3(PT), lds2, s, samples, frames, ids + b0, plans,
                                    twpool, ws, ws_stride, (int)kp.sparse_inv);

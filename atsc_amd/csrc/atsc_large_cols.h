@@ -93,7 +93,12 @@ DEVI void dft27f(float2 (&a)[27])
 constexpr int CT = 192;          // threads of a column-pass workgroup (12 x 16; q = 0..8 work)
 constexpr uint32_t CSI = 17;     // tile row stride in points (16 columns + 1)
 
-__global__ __launch_bounds__(CT) void k_large_cols243(const double *__restrict__ samples,
+// STATS: minimum, maximum and the fractional flag of the frame ride along (optimizer/utils.rs:39-89): the pass reads
+// every sample exactly once, as (x[j], x[j + 1]) pairs, so k_large_stats' separate walk over the samples is not
+// needed (the run starts, which need every sample's predecessor, are counted by k_large_poly1's contiguous walk).
+// Needs the paired-load form (even padding, 16-byte aligned frame): the caller falls back to k_large_stats otherwise.
+template <bool STATS>
+__global__ __launch_bounds__(CT, 3) void k_large_cols243(const double *__restrict__ samples,
                                                       const DevFrame *__restrict__ frames,
                                                       const uint32_t *__restrict__ ids,
                                                       const DevPlan *__restrict__ plans,
@@ -102,6 +107,8 @@ __global__ __launch_bounds__(CT) void k_large_cols243(const double *__restrict__
 {
     __shared__ float2 w1[243];
     __shared__ float2 T[243 * CSI];
+    __shared__ double sred[8];
+    __shared__ uint32_t ured[12];
     const DevPlan *P;
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, P);
     const uint32_t c0 = blockIdx.x * FB;
@@ -115,22 +122,36 @@ __global__ __launch_bounds__(CT) void k_large_cols243(const double *__restrict__
     const bool live = q < 9 && n2 < f.M2;
     for (uint32_t e = tid; e < 243; e += CT) w1[e] = tw[e * (f.M2 * f.sc)];
     float2 a[27];
+    double smn = __longlong_as_double(0x7ff0000000000000ll), smx = -smn;
+    uint32_t sfrac = 0;
+    const bool pairs = f.half && ((f.pre & 1u) == 0) && ((f.n & 1u) == 0) && (((uintptr_t)f.xs & 15u) == 0);
     {
         // fft.rs:184-204 (edge-replicated padding), then `as f32`; even L: point i = (g[2i], g[2i+1])
-        const bool pairs = f.half && ((f.pre & 1u) == 0) && ((f.n & 1u) == 0) && (((uintptr_t)f.xs & 15u) == 0);
         if (live && pairs) {
             double2 v[27];
 #pragma unroll
             for (int aa = 0; aa < 27; ++aa) {
                 const uint32_t i = f.M2 * (9u * aa + q) + n2;
-                int32_t j = (int32_t)(2 * i) - (int32_t)f.pre;  // even; a pair never straddles a frame edge
-                j = j < 0 ? 0 : (j >= (int32_t)f.n ? (int32_t)f.n - 2 : j);
+                const int32_t j2 = (int32_t)(2 * i) - (int32_t)f.pre;  // even; a pair never straddles a frame edge
+                const int32_t j = j2 < 0 ? 0 : (j2 >= (int32_t)f.n ? (int32_t)f.n - 2 : j2);
                 v[aa] = *(const double2 *)(f.xs + j);
-                if ((int32_t)(2 * i) - (int32_t)f.pre < 0) v[aa].y = v[aa].x;              // x[0], x[0]
-                if ((int32_t)(2 * i) - (int32_t)f.pre >= (int32_t)f.n) v[aa].x = v[aa].y;  // x[n-1], x[n-1]
             }
 #pragma unroll
-            for (int aa = 0; aa < 27; ++aa) a[aa] = make_float2((float)v[aa].x, (float)v[aa].y);
+            for (int aa = 0; aa < 27; ++aa) {
+                const uint32_t i = f.M2 * (9u * aa + q) + n2;
+                const int32_t j2 = (int32_t)(2 * i) - (int32_t)f.pre;
+                if (STATS) {  // (the padding repeats x[0] / x[n-1]: harmless for min / max / fractional)
+                    const double x0 = v[aa].x, x1 = v[aa].y;
+                    sfrac |= (frac_nonzero(x0) || frac_nonzero(x1)) ? 1u : 0u;
+                    if (x0 > smx) smx = x0;
+                    if (x0 < smn) smn = x0;
+                    if (x1 > smx) smx = x1;
+                    if (x1 < smn) smn = x1;
+                }
+                if (j2 < 0) v[aa].y = v[aa].x;              // x[0], x[0]
+                if (j2 >= (int32_t)f.n) v[aa].x = v[aa].y;  // x[n-1], x[n-1]
+                a[aa] = make_float2((float)v[aa].x, (float)v[aa].y);
+            }
         } else {
             auto g = [&](uint32_t j) -> float {
                 int32_t i = (int32_t)j - (int32_t)f.pre;
@@ -145,9 +166,30 @@ __global__ __launch_bounds__(CT) void k_large_cols243(const double *__restrict__
             }
         }
     }
+    if (STATS) {
+        // the tile's record (three wavefronts; lanes that hold no real sample carry the neutral values)
+        const double wmn = wave_minmax_f64<true>(smn), wmx = wave_minmax_f64<false>(smx);
+        const uint32_t wfr = __ballot(sfrac != 0) ? 1u : 0u;
+        if ((tid & 63) == 0) {
+            sred[tid >> 6] = wmn; sred[4 + (tid >> 6)] = wmx;
+            ured[tid >> 6] = wfr;
+        }
+    }
     // n1 = 9 a + q, k1 = ka + 27 kq:  W243^{n1 k1} = W27^{a ka} . W243^{q ka} . W9^{q kq}
     dft27f(a);
-    __syncthreads();  // w1
+    __syncthreads();  // w1, sred / ured
+    if (STATS && tid == 0 && blockIdx.x < TST_MAX) {
+        TileStats t;
+        t.mn = sred[0]; t.mx = sred[4];
+        for (int w = 1; w < CT / 64; ++w) {
+            if (sred[w] < t.mn) t.mn = sred[w];
+            if (sred[4 + w] > t.mx) t.mx = sred[4 + w];
+        }
+        t.frac = (ured[0] | ured[1] | ured[2]) ? 1u : 0u;
+        t.runs = t.ibytes = 0;  // (counted by k_large_poly1)
+        t.pad = pairs ? 1u : 0u;
+        ((TileStats *)(f.ws + lay.o_tst))[blockIdx.x] = t;
+    }
     if (q < 9) {
 #pragma unroll
         for (int ka = 1; ka < 27; ++ka) a[ka] = cmulc(a[ka], w1[q * ka]);
@@ -235,6 +277,131 @@ DEVI void dft_pow2f(float2 (&a)[N])  // forward, natural order in and out, N = 1
 }
 
 constexpr int RT = 256;  // threads of a row-pass workgroup
+
+// First trip of the polynomial ladder (polynomial.rs:209-277: points = max(3, n / 100), the plan's pstep[0] / pK[0]) for
+// one piece of 1024 samples, by a 256-thread workgroup -- the arithmetic of k_large_poly1, sample for sample; the
+// piece's share of the MAPE sum and its run starts (rle.rs:142-189) go to the workspace as plain stores.  Runs as extra
+// workgroups of the row pass's launch (the two are independent: one less launch boundary, and the latencies of one
+// hide behind the other's).  Clamp range from the column tiles' records (k_large_cols243<true>).
+constexpr uint32_t PCH = 4096;  // = LCH: the pieces are k_large_poly1's chunks, their sums land where its sums would
+DEVI void poly1_piece(const double *xs, const DevPlan &P, unsigned char *ws, const LargeWs &lay, uint32_t piece,
+                      unsigned char *lds)
+{
+    double4 *hbt = (double4 *)lds;                    // 256 x 32 B
+    double2 *mms = (double2 *)(lds + 8192);           // 512 segments at most (step >= 8)
+    double *red = (double *)(lds + 8192 + 16 * 512);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = P.n, c0 = piece * PCH;
+    if (c0 >= n) return;
+    const uint32_t c1 = min(c0 + PCH, n);
+    const uint32_t step = P.pstep[0], K = P.pK[0];
+    if (step < 16 || step > 256 || K < 2) return;  // (the fast path's frames have step = 100)
+    // clamp range: the column tiles' records, one per lane of the first wavefront, then broadcast
+    if (tid < 64) {
+        const uint32_t nt = (P.f4_m2 + FB - 1) / FB;
+        double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
+        if (tid < nt) {
+            const TileStats q = ((const TileStats *)(ws + lay.o_tst))[tid];
+            mn = q.mn; mx = q.mx;
+        }
+        mn = wave_minmax_f64<true>(mn);
+        mx = wave_minmax_f64<false>(mx);
+        if (tid == 0) { red[40] = mn; red[41] = mx; }
+    }
+    const uint32_t magic = P.pmagic[0];
+    const uint32_t gapL = (n - 1) - (K - 2) * step;
+    const double stepd = (double)step, gapLd = (double)gapL;
+    const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+    uint32_t sgA = __umulhi(c0, magic), sgB = __umulhi(c1 - 1, magic);
+    if (sgA > K - 2) sgA = K - 2;
+    if (sgB > K - 2) sgB = K - 2;
+    for (uint32_t sg = sgA + tid; sg <= sgB; sg += RT) {
+        double2 t = make_double2(0.0, 0.0);
+        if (sg >= 1 && sg + 2 < K) {
+            const uint32_t t0i = sg * step;
+            const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+            const uint32_t tmi = (sg - 1) * step;
+            const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+            const double t0 = (double)t0i, t1 = (double)t1i;
+            const double v0 = xs[t0i], v1 = xs[t1i], vm = xs[tmi], vp = xs[tpi];
+            t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+            t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+        }
+        mms[sg - sgA] = t;
+    }
+    for (uint32_t r = tid; r < step; r += RT) {
+        const double nt = div_small((double)r, stepd, ry);
+        const double t2 = nt * nt;
+        const double t3 = t2 * nt;
+        const double two_t3 = t3 * 2.0;
+        const double two_t2 = t2 * 2.0;
+        const double three_t2 = t2 * 3.0;
+        double4 h;
+        h.x = two_t3 - three_t2 + 1.0;
+        h.y = t3 - two_t2 + nt;
+        h.z = three_t2 - two_t3;
+        h.w = t3 - t2;
+        hbt[r] = h;
+    }
+    __syncthreads();
+    const double smin = red[40], smax = red[41];
+    double s = 0.0;
+    uint32_t runs = 0, ib = 0;
+    constexpr uint32_t SPB4 = 4;  // samples of a thread in flight
+    for (uint32_t b0 = c0; b0 < c1; b0 += SPB4 * RT) {
+        double g[SPB4], v0[SPB4], v1[SPB4], pv[SPB4];
+#pragma unroll
+        for (uint32_t u = 0; u < SPB4; ++u) {
+            const uint32_t i = b0 + u * RT + tid;
+            g[u] = v0[u] = v1[u] = pv[u] = 0.0;
+            if (i < c1) {
+                uint32_t sg = __umulhi(i, magic);
+                if (sg > K - 2) sg = K - 2;
+                const uint32_t t0i = sg * step;
+                g[u] = xs[i];
+                v0[u] = xs[t0i];
+                v1[u] = xs[(sg == K - 2) ? (n - 1) : t0i + step];
+                if (i) pv[u] = xs[i - 1];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < SPB4; ++u) {
+            const uint32_t i = b0 + u * RT + tid;
+            if (i >= c1) continue;
+            if (i == 0 || g[u] != pv[u]) { ++runs; ib += vlen(i); }
+            double sv;
+            if (i == n - 1) {
+                sv = g[u];
+            } else {
+                uint32_t sg = __umulhi(i, magic);
+                if (sg > K - 2) sg = K - 2;
+                const uint32_t t0i = sg * step;
+                const bool last = (sg == K - 2);
+                if (sg > 0 && !last) {
+                    const double2 t = mms[sg - sgA];
+                    const double4 h = hbt[i - t0i];
+                    sv = v0[u] * h.x + t.x * h.y + v1[u] * h.z + t.y * h.w;
+                } else {
+                    const double nt = div_small((double)(i - t0i), last ? gapLd : stepd, last ? ryL : ry);
+                    sv = v0[u] * (1.0 - nt) + v1[u] * nt;
+                }
+            }
+            double o = div1e5(round(sv * 100000.0));
+            if (o < smin) o = smin;
+            else if (o > smax) o = smax;
+            s += fabs((o - g[u]) / g[u]);
+        }
+    }
+    int parity = 0;
+    s = block_sum_f64<RT / 64>(s, red, parity);
+    runs = block_sum_u32<RT / 64>(runs, red, parity);
+    ib = block_sum_u32<RT / 64>(ib, red, parity);
+    if (tid == 0) {
+        ((double *)(ws + lay.o_part))[piece] = s;  // where k_large_poly1 leaves its chunk sums
+        ((uint2 *)(ws + lay.o_part + 1536))[piece] = make_uint2(runs, ib);
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ samples,
                                                       const DevFrame *__restrict__ frames,
@@ -242,14 +409,19 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
                                                       const DevPlan *__restrict__ plans,
                                                       const float2 *__restrict__ twpool,
                                                       unsigned char *__restrict__ ws_base, uint64_t ws_stride,
-                                                      int sparse_inv)
+                                                      int sparse_inv, uint32_t row_tiles)
 {
     constexpr uint32_t M2 = 9 * P, BS = P + 1, ZS = M2 + 1;
     constexpr uint32_t NPT = (FB * 9 * BS > FB * ZS) ? FB * 9 * BS : FB * ZS;
     __shared__ float2 w2[M2];
-    __shared__ float2 T[NPT];
+    __shared__ __attribute__((aligned(16))) float2 T[NPT];
+    static_assert(NPT * 8 >= 8192 + 16 * 512 + 512, "the polynomial pieces borrow the tile buffer (basis, tangents, 48 doubles)");
     const DevPlan *Pl;
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, Pl);
+    if (blockIdx.x >= row_tiles) {  // workgroups behind the row tiles: pieces of the first polynomial trip
+        poly1_piece(f.xs, *Pl, f.ws, large_ws_layout(f.n, f.L, Pl->kcap), blockIdx.x - row_tiles, (unsigned char *)T);
+        return;
+    }
     const uint32_t M1 = f.M1, M = f.M;
     if (f.M2 != M2) return;
     const uint32_t half_pairs = (M1 - 1) / 2;

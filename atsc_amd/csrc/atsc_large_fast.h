@@ -105,11 +105,43 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     const float2 *tw = twpool + P.tw_off;
     uint8_t *out = slots + fr.slot_off;
 
-    // ---- statistics (k_large_stats): optimizer/utils.rs:39-113 ----
-    const LargeStats *lst = (const LargeStats *)(ws + lay.o_cnt);
+    // ---- statistics (k_large_stats, or the column tiles' and polynomial chunks' records): optimizer/utils.rs:39-113 ----
+    LargeStats *lst = (LargeStats *)(ws + lay.o_cnt);
+    FrameStats st;
+    if (prm.tile_stats) {
+        // one record per lane, combined by wavefront reductions (nothing here depends on an order)
+        double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
+        uint32_t fr_ = 0, ru = 0, ib = 0;
+        if (tid < 64) {
+            if (tid < (P.f4_m2 + FB - 1) / FB) {
+                const TileStats q = ((const TileStats *)(ws + lay.o_tst))[tid];
+                mn = q.mn; mx = q.mx; fr_ = q.frac;
+            }
+            if (tid < (n + LCH - 1) / LCH) {
+                const uint2 pc = ((const uint2 *)(ws + lay.o_part + 1536))[tid];
+                ru = pc.x; ib = pc.y;
+            }
+            mn = wave_minmax_f64<true>(mn);
+            mx = wave_minmax_f64<false>(mx);
+            fr_ = __ballot(fr_ != 0) ? 1u : 0u;
+            ru = wave_sum_u32(ru);
+            ib = wave_sum_u32(ib);
+            if (tid == 0) {
+                bcd[1] = mn; bcd[2] = mx;
+                bc[12] = fr_; bc[13] = ru; bc[14] = ib;
+                // k_compress_large<0>, behind this path, reads the combined record (`zeros` is the row pass's)
+                lst->frac = fr_; lst->runs = ru; lst->ibytes = ib;
+                lst->kmin = f64_key(mn); lst->kmax = f64_key(mx);
+            }
+        }
+        __syncthreads();
+        st.mn = bcd[1]; st.mx = bcd[2]; st.frac = bc[12]; st.runs = bc[13]; st.ibytes = bc[14];
+    } else {
+        st = frame_stats(ws, lay, false, 0);
+    }
     const double x0 = xs[0];
     if (!(x0 == x0)) return;  // a NaN first sample keeps the scan's start value: left to the general kernel
-    const double smin = f64_unkey(lst->kmin), smax = f64_unkey(lst->kmax);
+    const double smin = st.mn, smax = st.mx;
     if (smin == 0.0 || smax == 0.0) return;  // the first zero of either sign has to be looked up
     uint32_t bitdepth;
     {
@@ -117,7 +149,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         bool fz;
         split_n(smax, maxi, fz);
         split_n(smin, mini, fz);
-        bitdepth = lst->frac ? 0u : bitdepth_of(maxi, mini);
+        bitdepth = st.frac ? 0u : bitdepth_of(maxi, mini);
     }
     if (smin == smax) {  // frame/mod.rs:82-88
         if (tid == 0) {
@@ -141,12 +173,12 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         if (can_win(size, owner)) { best_size = size; best_owner = owner; }
     };
     // ---- RLE bound (rle.rs:142-189): run count and index bytes come with the statistics ----
-    const uint32_t rle_R = lst->runs, rle_ib = lst->ibytes;
+    const uint32_t rle_R = st.runs, rle_ib = st.ibytes;
     const uint32_t rle_lb = 3 + rle_ib + (rle_R >= 2 ? 2u : 1u) * ((bitdepth == 0 ? 8u : 1u) + 1);
 
     // ---- polynomial, first trip (polynomial.rs:209-277): the chunk sums of k_large_poly1, in chunk order ----
     const uint32_t pstep = P.pstep[0], pK = P.pK[0];
-    if (!(pstep > 1 && pstep <= 256 && pK >= 2)) return;
+    if (!(pstep >= 16 && pstep <= 256 && pK >= 2)) return;
     if (tid == 0) {
         double s = 0.0;
         const double *part = (const double *)(ws + lay.o_part);
