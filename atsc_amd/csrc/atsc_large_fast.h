@@ -28,6 +28,7 @@ constexpr uint32_t FAST_OWN = 4608;        // positions below bins - 65536 = 444
 constexpr uint32_t FAST_LIST_OFF = 0, FAST_BOUNDS_OFF = 65536, FAST_KEYS_OFF = 69632;  // inside buffer B
 constexpr uint32_t FAST_PARTIAL_OFF = 8192;  // inside buffer C (as TRIP_PARTIAL_OFF)
 
+
 DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t n, uint32_t bitdepth, uint32_t K,
                          uint32_t step, double smin, double smax, double err, uint32_t *aux, uint32_t *wsum)
 {
@@ -98,9 +99,11 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     uint32_t *bc = (uint32_t *)(smem + 128);
     double *bcd = (double *)(smem + 192);
     uint32_t *h2 = (uint32_t *)(smem + 512);
-    unsigned long long *own = (unsigned long long *)(smem + 512 + 8192);
+    uint32_t *dcnt = (uint32_t *)(smem + 512 + 8192);  // 2048 per-digit cursors
+    unsigned long long *own = (unsigned long long *)(smem + 512 + 16384);
     unsigned long long *above = own + FAST_OWN;
-    unsigned long long *cand = above + FAST_K_MAX;
+    unsigned long long *sorted = above + FAST_K_MAX;
+    unsigned long long *cand = sorted + FAST_K_MAX;
     const double *xs = samples + fr.sample_off;
     const float2 *tw = twpool + P.tw_off;
     uint8_t *out = slots + fr.slot_off;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     FSTAMP(1);  // 1: statistics, polynomial trip 1, bounds
     // ---- the K1 largest norms (fft.rs:231-257), as a set ----
     const uint32_t *nbits = (const uint32_t *)(ws + lay.o_nb);
-    for (uint32_t i = tid; i < 2048; i += LT) h2[i] = 0;
+    for (uint32_t i = tid; i < 2048; i += LT) { h2[i] = 0; dcnt[i] = 0; }
     for (uint32_t i = tid; i < FAST_OWN; i += LT) own[i] = 0ull;
     if (tid < 16) bc[tid] = 0;
     if (tid == 0) bc[4] = 0xFFFFFFFFu;
@@ -264,13 +267,10 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
             const uint32_t d = v >> 20;
             const bool ab = in && d > dstar, cd = in && d == dstar;
             const unsigned long long key = ((unsigned long long)(~v) << 32) | (unsigned long long)k;
-            const uint64_t ma = __ballot(ab), mc = __ballot(cd);
-            if (ma) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&bc[2], (uint32_t)__popcll(ma));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (ab) above[base + (uint32_t)__popcll(ma & lt)] = key;
-            }
+            const uint64_t mc = __ballot(cd);
+            // a bin above the threshold digit goes straight into its digit's stretch of the final order: h2[] (scanned)
+            // holds the number of bins with a larger digit, i.e. where the stretch starts
+            if (ab) above[h2[2047u - d] + atomicAdd(&dcnt[2047u - d], 1u)] = key;
             if (mc) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&bc[3], (uint32_t)__popcll(mc));
@@ -301,6 +301,17 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         }
         __syncthreads();
     }
+    // the payload lists the bins by descending norm, equal norms by position (fft.rs:119-130, 231-257; the large tier's
+    // order): the stretches are in place, inside a stretch a key's place is the number of smaller keys in it
+    for (uint32_t i = tid; i < n_above; i += LT) {
+        const unsigned long long key = above[i];
+        const uint32_t di = 2047u - ((~(uint32_t)(key >> 32)) >> 20);
+        const uint32_t gb = h2[di], ge = gb + dcnt[di];
+        uint32_t rank = 0;
+        for (uint32_t j = gb; j < ge; ++j) rank += above[j] < key ? 1u : 0u;
+        sorted[gb + rank] = key;
+    }
+    __syncthreads();
     FSTAMP(3);  // 3: digit, collection
     // the `take` smallest candidate keys (norm descending, position ascending): radix select of the take-th smallest
     // 37-bit key -- 20 norm bits below the digit, 17 position bits -- 11 bits a level
@@ -343,13 +354,28 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     unsigned long long *skey = (unsigned long long *)(Bb + FAST_KEYS_OFF);
     const float2 *spec = (const float2 *)(ws + lay.o_a);
     uint32_t big = 0;
-    if (tid == 0) bc[2] = n_above;  // next free slot behind the bins above the digit
+    if (tid == 0) bc[2] = 0;
     __syncthreads();
     {
         auto k37 = [](unsigned long long key) -> unsigned long long {
             return ((key >> 32) & 0xFFFFFull) << 17 | (key & 0x1FFFFull);
         };
-        auto admit = [&](uint32_t i, unsigned long long key) {
+        // the candidates that made it: behind the stretches, in order among themselves
+        for (uint32_t i = tid; i < n_cand; i += LT) {
+            const unsigned long long key = cand[i];
+            if (k37(key) <= prefix) above[atomicAdd(&bc[2], 1u)] = key;  // (the stretches live in sorted[] now)
+        }
+        __syncthreads();
+        if (bc[2] != take) return;  // (cannot happen: the select is exact)
+        for (uint32_t i = tid; i < take; i += LT) {
+            const unsigned long long key = above[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < take; ++j) rank += above[j] < key ? 1u : 0u;
+            sorted[n_above + rank] = key;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < K1; i += LT) {
+            const unsigned long long key = sorted[i];
             const uint32_t pos = (uint32_t)(key & 0xffffffffull);
             const float2 z = spec[pos];
             sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
@@ -357,11 +383,6 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
             const uint32_t p16 = pos & 0xffffu;
             big += p16 >= 251 ? 1u : 0u;
             if (p16 < FAST_OWN) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
-        };
-        for (uint32_t i = tid; i < n_above; i += LT) admit(i, above[i]);
-        for (uint32_t i = tid; i < n_cand; i += LT) {
-            const unsigned long long key = cand[i];
-            if (k37(key) <= prefix) admit(atomicAdd(&bc[2], 1u), key);
         }
     }
     {
@@ -369,7 +390,6 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         big = block_sum_u32<LW>(big, (double *)(smem + 256), parity);
     }
     __syncthreads();
-    if (bc[2] != K1) return;  // (cannot happen: the select is exact)
     FSTAMP(5);  // 5: admission
     // ---- the trip's packed-spectrum points, bucketed by k mod 243 (see sparse_bucket) ----
     // (the candidate list is done with: its LDS hosts the list)
@@ -696,17 +716,17 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     __syncthreads();
     uint32_t *wsum = (uint32_t *)smem;
     uint32_t *aux = (uint32_t *)(smem + 512);                       // 2048 u32
-    unsigned long long *keys = (unsigned long long *)(smem + 512 + 8192);  // 2048 u64
-    uint32_t *pay = (uint32_t *)(keys + 2048);                       // 2048 u32
     const double *xs = samples + fr.sample_off;
     uint8_t *out = slots + fr.slot_off;
     const double me = prm.max_err;
-    double s = 0.0;
-    {
+    if (tid == 0) {  // the tiles' sums, in tile order
+        double s = 0.0;
         const double *part = (const double *)(ws + lay.o_c + FAST_PARTIAL_OFF);
         for (uint32_t t = 0; t < FAST_TILES; ++t) s += part[t];
+        *(double *)(smem + 256) = s;
     }
-    const double cur = s / (double)L;  // mean over the padded samples (fft.rs:345)
+    __syncthreads();
+    const double cur = *(const double *)(smem + 256) / (double)L;  // mean over the padded samples (fft.rs:345)
     uint32_t best_size = f.best_size;
     int best_owner = f.best_owner;
     auto can_win = [&](uint32_t size_lb, int owner) {
@@ -728,19 +748,14 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
         fast_emit_poly(out, res[fid], xs, n, f.bitdepth, f.poly_K, f.poly_step, f.smin, f.smax, f.poly_err, aux, wsum);
     } else {
         // FFT payload (fft.rs:119-130): the bins by descending norm, equal norms by position (the large tier's order)
+        // (k_large_decide1 left sel[] in the payload's order)
         const Sel *sel = (const Sel *)(ws + lay.o_sel);
-        const unsigned long long *skey = (const unsigned long long *)(ws + lay.o_b + FAST_KEYS_OFF);
-        for (uint32_t i = tid; i < K1; i += LT) { keys[i] = skey[i]; pay[i] = i; }
-        __syncthreads();
-        uint32_t p2 = 1;
-        while (p2 < K1) p2 <<= 1;
-        block_sort<LW, false>((uint64_t *)keys, pay, K1, p2);
         const uint32_t hdr = 1 + vlen(K1);
-        for (uint32_t i = tid; i < K1; i += LT) aux[i] = vlen(sel[pay[i]].pos & 0xffffu) + 8;
+        for (uint32_t i = tid; i < K1; i += LT) aux[i] = vlen(sel[i].pos & 0xffffu) + 8;
         __syncthreads();
         const uint32_t body = block_excl_scan<LW>(aux, K1, wsum);
         for (uint32_t i = tid; i < K1; i += LT) {
-            const Sel e = sel[pay[i]];
+            const Sel e = sel[i];
             uint8_t *p = out + hdr + aux[i];
             p += put_varint(p, e.pos & 0xffffu);
             put_f32(p, e.re);
@@ -759,6 +774,6 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     if (tid == 0) fs->status = 2;
 }
 
-constexpr uint32_t FAST_D1_LDS = 512 + 8192 + 8 * (FAST_OWN + FAST_K_MAX + FAST_CAND_MAX);
+constexpr uint32_t FAST_D1_LDS = 512 + 16384 + 8 * (FAST_OWN + 2 * FAST_K_MAX + FAST_CAND_MAX);
 constexpr uint32_t FAST_TILE_LDS = 8 * (243 * CSI + 243 + FAST_MD) + 4 * 768;
-constexpr uint32_t FAST_D2_LDS = 512 + 8192 + 8 * 2048 + 4 * 2048;
+constexpr uint32_t FAST_D2_LDS = 512 + 8192;
