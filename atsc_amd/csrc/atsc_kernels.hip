@@ -1745,6 +1745,61 @@ __global__ __launch_bounds__(256) void k_pack_emit_big(const DevFrame *__restric
     if (whole + threadIdx.x < r.len) pd[whole + threadIdx.x] = src[whole + threadIdx.x];
 }
 
+
+// Few frames (a batch of large frames: 80 records of kilobytes): one launch instead of three.  A workgroup per frame
+// adds up the record lengths of the frames in front of its own -- at most PACK_SMALL_MAX of them, 16 bytes each, L2
+// resident -- and copies its payload 16 bytes per lane.  Same bytes as k_pack_scan1 + k_pack_emit (+ _big).
+constexpr uint32_t PACK_SMALL_MAX = 1024;
+__global__ __launch_bounds__(256) void k_pack_small(const DevFrame *__restrict__ frames, const DevResult *__restrict__ res,
+                                                    uint32_t n_frames, const uint8_t *__restrict__ slots,
+                                                    uint8_t *__restrict__ body, uint64_t body_cap,
+                                                    uint64_t *__restrict__ rec_off, uint8_t *__restrict__ chosen,
+                                                    double *__restrict__ err, const uint64_t *__restrict__ chain_in,
+                                                    uint64_t *__restrict__ chain_out)
+{
+    __shared__ uint32_t ws[8];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    uint32_t before = 0;
+    for (uint32_t g = tid; g < f; g += 256) {
+        const DevResult r = res[g];
+        before += rec_header_len(frames[g].n, r.chosen, r.len) + r.len;
+    }
+    before = wave_sum_u32(before);
+    if ((tid & 63) == 0) ws[tid >> 6] = before;
+    __syncthreads();
+    uint64_t off = (uint64_t)ws[0] + ws[1] + ws[2] + ws[3];  // (n_frames <= 1024 records of < 4 MB: the 32-bit partial sums hold)
+    if (chain_in) off += *chain_in;
+    const DevFrame fr = frames[f];
+    const DevResult r = res[f];
+    const uint32_t hl = rec_header_len(fr.n, r.chosen, r.len);
+    if (tid == 0) {
+        rec_off[f] = off;
+        if (chosen) chosen[f] = (uint8_t)r.chosen;
+        if (err) err[f] = r.err;
+        if (f == n_frames - 1) {
+            rec_off[n_frames] = off + hl + r.len;
+            if (chain_out) *chain_out = off + hl + r.len;
+        }
+    }
+    if (off + hl + r.len > body_cap) return;  // caller sized d_body too small; rec_off tells
+    uint8_t *dst = body + off;
+    if (tid == 0) {
+        uint8_t *p = dst;
+        *p++ = 41;
+        p += put_varint(p, fr.n);
+        p += put_varint(p, r.chosen);
+        p += put_varint(p, r.len);
+    }
+    const uint8_t *src = slots + fr.slot_off;
+    uint8_t *pd = dst + hl;
+    const uint32_t whole = r.len & ~15u;
+    for (uint32_t b = tid * 16; b < whole; b += 256 * 16) {
+        const uint4 v = *(const uint4 *)(src + b);
+        __builtin_memcpy(pd + b, &v, 16);
+    }
+    if (whole + tid < r.len) pd[whole + tid] = src[whole + tid];
+}
+
 // --------------------------------------------------------------------------------------------
 // Test hook (declared in atsc_internal.h, not part of the public ABI): the pop order of the heap replay
 // (hp_*) for a given array of norms, so that tests can hold it against the oracle's restatement of
@@ -1903,6 +1958,12 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
 {
     const uint64_t *chain_in = chain;
     uint64_t *chain_out = chain ? chain + 1 : nullptr;
+    if (n_frames <= 256 || (n_big * 4 >= n_frames && n_frames <= PACK_SMALL_MAX)) {
+        // few records (or mostly large frames' kilobyte payloads): one launch
+        hipLaunchKernelGGL(k_pack_small, dim3((uint32_t)n_frames), dim3(256), 0, s, frames, res, (uint32_t)n_frames, slots,
+                           body, body_cap, rec_off, chosen, err, chain_in, chain_out);
+        return hipGetLastError();
+    }
     const uint32_t nb = (uint32_t)((n_frames + PACK_CHUNK - 1) / PACK_CHUNK);
     hipLaunchKernelGGL(k_pack_scan1, dim3(nb), dim3(256), 0, s, frames, res, n_frames, local,
                        blocksum);
