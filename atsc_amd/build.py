@@ -15,7 +15,8 @@ CLI = os.path.join(HERE, "bin", "atsc")
 CLI_SRC = "atsc_cli.cpp"
 CLI2 = os.path.join(HERE, "bin", "csv-compressor")
 CLI2_SRC = "csv_compressor_cli.cpp"
-DEPS = SOURCES + ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
+DEPS = SOURCES + ["atsc_device.h", "atsc_internal.h", "atsc_large_cols.h", "atsc_large_fast.h",
+                  os.path.join("..", "..", "include", "atsc_hip.h")]
 # -ffp-contract=off: the f64 spline / rounding arithmetic must evaluate exactly as written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
@@ -37,12 +38,24 @@ def stale():
 
 
 OBJDIR = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
-HEADERS = ["atsc_device.h", "atsc_internal.h", os.path.join("..", "..", "include", "atsc_hip.h")]
+HEADERS = ["atsc_device.h", "atsc_internal.h", "atsc_large_cols.h", "atsc_large_fast.h",
+           os.path.join("..", "..", "include", "atsc_hip.h")]
 CFLAGS = [f for f in FLAGS if f != "-shared"] + os.environ.get("ATSC_BUILD_DEFS", "").split()
 
 
+def _flags_key():
+    return " ".join(CFLAGS)
+
+
 def _obj_stale(src, obj):
+    """An object is stale when a source or header is newer than it, or when it was compiled with other flags
+    (ATSC_BUILD_DEFS of a dev variant, a changed FLAGS): the flag string is kept next to the object."""
     if not os.path.exists(obj):
+        return True
+    try:
+        if open(obj + ".flags").read() != _flags_key():
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(obj)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in [src] + HEADERS)
@@ -60,8 +73,14 @@ def _compile_objects(force, verbose):
             cmd = [_hipcc()] + CFLAGS + ["-c", "-o", obj, os.path.join(CSRC, s)]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
-    bad = [s for s, p in jobs if p.wait() != 0]
+            jobs.append((s, obj, subprocess.Popen(cmd, cwd=CSRC)))
+    bad = []
+    for s, obj, p in jobs:
+        if p.wait() != 0:
+            bad.append(s)
+        else:
+            with open(obj + ".flags", "w") as f:
+                f.write(_flags_key())
     if bad:
         raise RuntimeError("hipcc failed on " + ", ".join(bad))
     return objs
@@ -71,7 +90,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     objs = _compile_objects(force, verbose)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc()] + [f for f in FLAGS if f != "-ffp-contract=off"] + ["-o", LIB] + objs  # the compile flags, -shared included
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -48,6 +48,10 @@ SIGNATURES = {
     "atsc_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "atsc_ctx_destroy": (None, [_vp]),
     "atsc_ctx_last_error": (C.c_char_p, [_vp]),
+    "atsc_ctx_trim": (C.c_int, [_vp]),
+    "atsc_release_caches": (None, []),
+    "atsc_host_register": (C.c_int, [_vp, C.c_uint64]),
+    "atsc_host_unregister": (C.c_int, [_vp]),
     "atsc_plan_create": (C.c_int, [_vp, _u64p, C.c_uint64, C.POINTER(_vp)]),
     "atsc_plan_destroy": (None, [_vp]),
     "atsc_plan_n_frames": (C.c_uint64, [_vp]),
@@ -69,6 +73,7 @@ SIGNATURES = {
     "atsc_compress_frames": (C.c_int, [_vp, _f64p, _u64p, C.c_uint64, C.c_int, C.c_int, C.c_float,
                                        C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u8p, _f64p]),
     "atsc_shard_range": (None, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
+    "atsc_shard_range_weighted": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _u64p]),
     "atsc_compress_frames_sharded": (C.c_int, [C.POINTER(_vp), C.c_uint32, _f64p, _u64p, C.c_uint64, C.c_int, C.c_int,
                                                C.c_float, C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u8p, _f64p]),
     "atsc_dplan_create": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_int, C.POINTER(_vp)]),

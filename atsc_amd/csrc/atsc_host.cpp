@@ -106,6 +106,8 @@ struct atsc_ctx {
     std::vector<CachedPlan> plan_cache;
     uint64_t plan_stamp = 0;
     hipStream_t work_stream = nullptr;
+    hipStream_t copy_stream = nullptr;             // host-to-device copies of the host-pointer entry points
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};    // "part g's samples are on the device"
 };
 
 struct PlanTables {
@@ -346,11 +348,14 @@ static int class_of(uint32_t n, uint32_t L)
 // (cos, sin)(2 pi t / L), t < L, rounded from f64.  A 131072-sample frame's table is 139968 libm calls
 // twice over -- milliseconds, per plan and per decode plan -- so the tables are kept for the life of the
 // process (up to TW_CACHE_MAX entries in all; beyond that they are recomputed).
+static std::mutex g_tw_mu;
+static std::map<uint32_t, std::vector<float2>> g_tw_cache;
+static size_t g_tw_held = 0;
 static void twiddle_table(uint32_t L, float2 *out)
 {
-    static std::mutex mu;
-    static std::map<uint32_t, std::vector<float2>> cache;
-    static size_t held = 0;
+    std::mutex &mu = g_tw_mu;
+    std::map<uint32_t, std::vector<float2>> &cache = g_tw_cache;
+    size_t &held = g_tw_held;
     const size_t TW_CACHE_MAX = 16u << 20;  // 16 M entries = 128 MB
     {
         std::lock_guard<std::mutex> g(mu);
@@ -553,6 +558,9 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     for (auto &cp : ctx->plan_cache) atsc_plan_destroy(cp.plan);
     ctx->plan_cache.clear();
     if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (auto &ev : ctx->ev_copy)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     for (auto &cs : ctx->chain_streams)
@@ -563,6 +571,42 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     // blocks still held by plans that outlive their context (a contract violation) are left alone: their
     // owners would otherwise free them a second time
     delete ctx;
+}
+// Gives back what the context keeps for the next call: the device blocks of its pool that no plan holds, and the
+// plans it caches by frame layout for the host-pointer entry points (their scratch sets, workspaces and tables).
+extern "C" int atsc_ctx_trim(atsc_ctx *ctx)
+{
+    ATSC_API_BEGIN
+    if (!ctx) return ATSC_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto &cp : ctx->plan_cache) atsc_plan_destroy(cp.plan);  // (synchronises the device)
+    ctx->plan_cache.clear();
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (auto &b : ctx->pool_free_list) (void)hipFree(b.first);
+    ctx->pool_free_list.clear();
+    ctx->pool_held = 0;
+    return ATSC_OK;
+    ATSC_API_END
+}
+// Process-wide caches: the host block kept for the next decoded result (atsc_free) and the twiddle tables.
+extern "C" void atsc_release_caches(void)
+{
+    atsc::big_trim();
+    std::lock_guard<std::mutex> g(g_tw_mu);
+    g_tw_cache.clear();
+    g_tw_held = 0;
+}
+// Page-locks caller memory for the host-pointer entry points (hipHostRegister): the host-to-device copies of
+// atsc_compress_frames / atsc_compress_data then run at the link's rate and asynchronously.
+extern "C" int atsc_host_register(void *p, uint64_t bytes)
+{
+    if (!p || !bytes) return ATSC_E_INVALID;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? ATSC_OK : ATSC_E_HIP;
+}
+extern "C" int atsc_host_unregister(void *p)
+{
+    if (!p) return ATSC_E_INVALID;
+    return hipHostUnregister(p) == hipSuccess ? ATSC_OK : ATSC_E_HIP;
 }
 extern "C" const char *atsc_ctx_last_error(const atsc_ctx *ctx)
 {
@@ -1214,6 +1258,16 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         else {
             UniArgs u = plan->class_uni[c];
             u.adaptive = (ids_main != plan->d_ids) ? 1u : 0u;
+            u.count = plan->class_count[c];
+            u.spread = 0;
+            static const bool no_spread = getenv("ATSC_NO_SPREAD") != nullptr;
+            if (u.enabled && !u.adaptive && !no_spread && u.count >= 4096) {
+                // a stride near count / golden ratio, made coprime to count
+                uint32_t sp = (uint32_t)((double)u.count * 0.6180339887) | 1u;
+                auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+                while (gcd(sp, u.count) != 1) sp += 2;
+                u.spread = sp % u.count;
+            }
             e = launch_compress_class(c, plan->class_count[c], plan->class_lds[c], d_samples,
                                       plan->d_frames, ids_main + plan->class_first[c],
                                       plan->tabs.d_plans, plan->tabs.d_tw, prm, S.d_slots,
@@ -1348,6 +1402,10 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     };
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->work_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->work_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (auto &ev : ctx->ev_copy) HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     const uint64_t ns = frame_off[n_frames] - frame_off[0];
     // parts: only for uniform frames of the LDS-resident tiers (the large tier runs best with every frame in one launch)
     const uint64_t fl = frame_off[1] - frame_off[0];
@@ -1400,10 +1458,17 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
         const uint64_t s0 = frame_off[pt[g].f0] - frame_off[0], s1 = frame_off[pt[g].f1] - frame_off[0];
         // (pieces of at most 16 MB: one pageable copy of 40 MB and more has been seen to take 10-15 ms -- the
         // runtime pins such a source on the fly -- where the same bytes in smaller calls go at the link's rate)
+        // The copies go to a stream of their own and the kernels wait for an event behind them: the order does not
+        // rest on a blocking copy having landed when it returns.  From pageable memory the call still returns only
+        // once the bytes are staged, i.e. part g + 1 is being copied while part g's kernels run; from memory the
+        // caller registered (atsc_host_register) the copies are true DMA transfers and the host runs ahead.
         for (uint64_t c0 = s0; c0 < s1; c0 += (2u << 20)) {
             const uint64_t c1 = std::min<uint64_t>(s1, c0 + (2u << 20));
-            FCHK(hipMemcpy(d_x + c0, samples + frame_off[0] + c0, (c1 - c0) * sizeof(double), hipMemcpyHostToDevice));
+            FCHK(hipMemcpyAsync(d_x + c0, samples + frame_off[0] + c0, (c1 - c0) * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->copy_stream));
         }
+        FCHK(hipEventRecord(ctx->ev_copy[g & 1], ctx->copy_stream));
+        FCHK(hipStreamWaitEvent(ws, ctx->ev_copy[g & 1], 0));
         lap("  part copy");
         if (nonfinite) FCHK(launch_nonfinite_flag(d_x + s0, s1 - s0, (uint32_t *)(d_off + n_frames + 2 * parts + 1), ws));
         rc = compress_impl(ctx, pt[g].plan, d_x + s0, compressor, bounded, max_error, sample_level, d_body, bound,
@@ -1487,6 +1552,23 @@ extern "C" void atsc_shard_range(uint64_t n_units, uint32_t rank, uint32_t world
     const uint64_t b = (uint64_t)rank * base + std::min<uint64_t>(rank, rem);
     if (begin) *begin = b;
     if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
+
+// The same with rank 0 carrying root_weight_milli / 1000 times a peer's share (every peer's records cross one link to
+// the root, the root's stay where they are: atsc_amd/parallel.py::shard_range_weighted is this function).
+extern "C" void atsc_shard_range_weighted(uint64_t n_units, uint32_t rank, uint32_t world, uint32_t root_weight_milli,
+                                          uint64_t *begin, uint64_t *end)
+{
+    if (world == 0) world = 1;
+    const uint64_t w0 = root_weight_milli ? root_weight_milli : 1;
+    const uint64_t total = w0 + 1000ull * (world - 1);
+    auto cut = [&](uint64_t r) -> uint64_t {
+        if (r == 0) return 0;
+        if (r >= world) return n_units;
+        return (uint64_t)(((unsigned __int128)n_units * (w0 + 1000ull * (r - 1))) / total);
+    };
+    if (begin) *begin = cut(rank);
+    if (end) *end = cut((uint64_t)rank + 1);
 }
 
 // One process, several GPUs: shard r = atsc_shard_range(n_frames, r, n_ctx) goes through ctxs[r] on a

@@ -154,6 +154,7 @@ struct UniArgs {
     uint64_t slot_stride;
     uint32_t n;
     uint32_t plan;
+    uint32_t spread, count;  // spread != 0: workgroup b takes frame (b * spread) % count of the class (spread coprime to count)
 };
 
 // parsed frame record for decompression
@@ -231,6 +232,7 @@ static inline bool host_next_record(const uint8_t *b, uint64_t len, uint64_t &po
 namespace atsc {
 void *big_alloc(size_t bytes);
 bool big_release(void *p);  // true: p was a big_alloc block and has been taken care of
+void big_trim();            // frees the kept block
 }  // namespace atsc
 
 // atsc_compress_frames with the output allocated by the library once its length is known (*out: malloc'd,

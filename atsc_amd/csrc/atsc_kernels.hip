@@ -293,7 +293,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     }
 #endif
     if (uni.enabled) {
-        const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0 : blockIdx.x;
+        // Index order starts the frames series block by series block: when the last block of a batch is a busy one the
+        // launch drains on a few CUs.  Without a cost order the frames are dealt with a fixed stride instead, so that
+        // every stretch of the launch is a mix of the batch's blocks (results are positional: nothing else changes).
+        const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0
+                           : uni.spread ? (uint32_t)(((uint64_t)blockIdx.x * uni.spread) % uni.count) : blockIdx.x;
         fid = uni.fid0 + r;
         fr.sample_off = uni.sample_off0 + (uint64_t)r * uni.n;
         fr.slot_off = uni.slot_off0 + (uint64_t)r * uni.slot_stride;

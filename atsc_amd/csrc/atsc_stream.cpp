@@ -70,10 +70,16 @@ static std::mutex g_big_mu;
 static std::map<void *, size_t> g_big_live;   // blocks handed out by big_alloc
 static void *g_big_kept = nullptr;            // the block released last, still resident
 static size_t g_big_kept_size = 0;
-static const size_t BIG_MIN = 8u << 20, BIG_KEEP_MAX = 2ull << 30;
+static const size_t BIG_MIN = 8u << 20;
+static size_t g_big_keep_max = 2ull << 30;    // ATSC_BIG_KEEP_MAX (bytes) / atsc_release_caches
 void *big_alloc(size_t bytes)
 {
     if (bytes < BIG_MIN) return malloc(bytes ? bytes : 1);
+    static const bool env_read = [] {
+        if (const char *e = getenv("ATSC_BIG_KEEP_MAX")) g_big_keep_max = (size_t)strtoull(e, nullptr, 10);
+        return true;
+    }();
+    (void)env_read;
     std::lock_guard<std::mutex> g(g_big_mu);
     void *p = nullptr;
     size_t sz = bytes;
@@ -95,7 +101,7 @@ bool big_release(void *p)
     if (it == g_big_live.end()) return false;
     const size_t sz = it->second;
     g_big_live.erase(it);
-    if (sz <= BIG_KEEP_MAX && sz >= g_big_kept_size) {  // keep the larger of the two
+    if (sz <= g_big_keep_max && sz >= g_big_kept_size) {  // keep the larger of the two
         if (g_big_kept) free(g_big_kept);
         g_big_kept = p;
         g_big_kept_size = sz;
@@ -103,6 +109,14 @@ bool big_release(void *p)
         free(p);
     }
     return true;
+}
+// the kept block goes back to the allocator (atsc_release_caches)
+void big_trim()
+{
+    std::lock_guard<std::mutex> g(g_big_mu);
+    if (g_big_kept) free(g_big_kept);
+    g_big_kept = nullptr;
+    g_big_kept_size = 0;
 }
 }  // namespace atsc
 

@@ -253,10 +253,12 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
             "note": "device resident; the reference chunker's framing of the same batches (the atsc CLI's framing)"}
 
 
-ROTATE = 4          # resident batches the timed loop cycles through (N = 1 workload)
+ROTATE = 5          # resident batches the timed loop cycles through (N = 1 workload); coprime with the chains
 C3_SERIES = 4096    # configs[3]: 4096 series x 262144 samples = 2^30
 C3_PER = 262144
 C3_ERROR_PCT = 1
+C3_ROTATE = 2       # resident batches per rank at N > 1 (different series values, same shape)
+XGMI_LINK_GBS = 70.0  # per-direction rate of one xGMI link assumed by --root-weight auto
 
 
 def main():
@@ -270,17 +272,20 @@ def main():
                     help="auto: configs[2] at N = 1 (the metric's config), configs[3]'s per-rank share at N > 1")
     ap.add_argument("--series", type=int, default=C3_SERIES, help="config3 only: total series over all ranks")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="pack the records on the codec stream (atsc_compress_plan_dev) instead of "
-                         "overlapping them with the next step's codecs (atsc_compress_plan_dev_pipelined)")
-    ap.add_argument("--chains", action="store_true",
-                    help="N = 1: also time the batches dealt over four independent chains (`value_chains`); the "
-                         "large-tier and host-pointer measurements are skipped in such a run (streams stay mapped "
-                         "to the few hardware queues once they exist: the measurements would disturb one another)")
+                    help="plain single-stream calls (atsc_compress_plan_dev) instead of the chained entry point "
+                         "(atsc_compress_plan_dev_pipelined)")
+    ap.add_argument("--chains", type=int, default=0, help="chains of the pipelined entry point (1..4; 0: the library's default, 2)")
     ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
     ap.add_argument("--adaptive-order", action="store_true",
                     help="start the frames costliest-first instead of in index order (cost = shader clocks of the same "
                          "frame slot in an earlier batch of the same chain); off by default: with two chains in flight the "
                          "drain of one launch is covered by the other chain's kernel and `value` leans on no hint")
+    ap.add_argument("--root-weight", default="1",
+                    help="N > 1: rank 0's share relative to a peer's (atsc_shard_range_weighted); 'auto' = (B / R) / T1 from "
+                         "an untimed single-rank measurement and %.0f GB/s per link" % XGMI_LINK_GBS)
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: every rank keeps its records (the reference writes one .bro per input file, "
+                         "main.rs:121-124): no collective at all in the timed loop")
     args = ap.parse_args()
 
     import torch
@@ -322,66 +327,112 @@ def main():
     if workload == "auto":
         workload = "config2" if world == 1 else "config3"
     ctx = atsc_amd.Context(dev_index)
+    if args.chains:
+        ctx.set_chains(args.chains)
+    ctx.set_adaptive_order(bool(args.adaptive_order))
+    root_weight = 1.0
     if workload == "config2":
-        # BASELINE.json configs[2]: one 10,485,760-sample series per batch, classes cycled per 65536-sample
-        # block.  ROTATE different series are resident and the timed loop walks through them, so a step never
-        # sees the batch whose costs ordered its launch: the hint is a prediction from another batch of the
-        # same layout, as in a service that gets the next window of the same series.
+        # BASELINE.json configs[2]: one 10,485,760-sample series per batch, classes cycled per 65536-sample block.
+        # ROTATE different series are resident, each with ANOTHER block -> class mapping (class = (block + 2 b) % 5 for
+        # batch b), and the timed loop walks through them: no step sees a batch it has seen before in the same slot of
+        # a chain, and an optional cost hint (--adaptive-order) comes from a batch with a different layout.
         error_pct = ERROR_PCT
         n_local = N_SAMPLES
-        xs = [H.synth_series(rank * ROTATE + b, N_SAMPLES) for b in range(ROTATE)]
+        xs = [H.synth_series(rank * ROTATE + b, N_SAMPLES, class_shift=2 * b) for b in range(ROTATE)]
         d_xs = [torch.from_numpy(v).to(dev) for v in xs]
         units_total = world * N_SAMPLES
         desc = ("BASELINE.json configs[2] per GPU: 10,485,760 f64 samples, 40960 frames x 256, --compressor auto, "
                 "e=5%% (max_error=(float)5/100), classes C0-C4 cycled per 65536-sample block, inputs resident in "
-                "HBM; the timed loop rotates over %d different resident batches (series ids %d..%d)"
-                % (ROTATE, rank * ROTATE, rank * ROTATE + ROTATE - 1))
+                "HBM; the timed loop rotates over %d different resident batches (series ids %d..%d, batch b with the "
+                "block -> class mapping shifted by 2 b)" % (ROTATE, rank * ROTATE, rank * ROTATE + ROTATE - 1))
     else:
         # BASELINE.json configs[3]: 4096 series x 262,144 samples (2^30), class = series % 5, auto e=1%,
-        # series s on rank s / (4096 / N): total work fixed, per-rank share 4096 / N series.
+        # series s on rank s / (4096 / N): total work fixed, per-rank share 4096 / N series
+        # (rank 0 more than a peer with --root-weight).
         error_pct = C3_ERROR_PCT
-        sb, se = parallel.shard_range(args.series, rank, world)
-        n_local = (se - sb) * C3_PER
-        d_x = torch.empty(n_local, dtype=torch.float64, device=dev)
-        for s in range(sb, se):
-            d_x[(s - sb) * C3_PER:(s - sb + 1) * C3_PER] = H.synth_series_torch(torch, dev, s, C3_PER, s % 5)
-        d_xs = [d_x]
+        if args.root_weight == "auto":
+            root_weight = None  # decided below, from an untimed measurement
+        else:
+            root_weight = float(args.root_weight)
         xs = None
         units_total = args.series * C3_PER
-        desc = ("BASELINE.json configs[3]: %d series x 262,144 f64 samples (%d samples over all ranks), "
-                "class = series %% 5, --compressor auto, e=1%% (max_error=(float)1/100), 256-sample frames, series "
-                "sharded contiguously by rank (%d per rank), inputs resident in HBM, encoded records gathered to "
-                "rank 0 every step" % (args.series, units_total, se - sb))
+
     me = float(np.float32(error_pct) / np.float32(100))
-    off = np.arange(0, n_local + 1, FRAME, dtype=np.uint64)
-    plan = ctx.plan(off)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # Steady state of a compression service: batch after batch.  Two output sets; the record packing
-    # of step i runs on the context's pack stream and overlaps the frame codecs of step i+1 (and, for
-    # N > 1, so does the gather of step i, issued from a side stream that waits for that packing).
+    def c3_batch(sb, se, variant):
+        """Series sb..se-1 of configs[3]; variant v: series id s + v * C3_SERIES (same class, other values)."""
+        d_x = torch.empty((se - sb) * C3_PER, dtype=torch.float64, device=dev)
+        for s in range(sb, se):
+            d_x[(s - sb) * C3_PER:(s - sb + 1) * C3_PER] = H.synth_series_torch(torch, dev, s + variant * C3_SERIES, C3_PER, s % 5)
+        return d_x
+
+    if workload == "config3":
+        if root_weight is None:
+            # (B / R) / T1: a 64-series sample on this rank gives the codec rate and the record bytes per sample
+            root_weight = 1.0
+            if world > 1:
+                ns = 64
+                d_s = c3_batch(0, ns, 0)
+                offs = np.arange(0, ns * C3_PER + 1, FRAME, dtype=np.uint64)
+                pl = ctx.plan(offs)
+                o = pl.alloc_outputs(torch, dev)
+                for _ in range(2):
+                    pl.compress(d_s, o, atsc_amd.AUTO, True, me, 0, stream)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    pl.compress(d_s, o, atsc_amd.AUTO, True, me, 0, stream)
+                torch.cuda.synchronize()
+                t1 = (time.perf_counter() - t0) / 4 * (args.series / ns)  # single-GPU codec time of the whole job
+                bts = float(o["rec_off"][-1].item()) * (args.series / ns)
+                pl.close()
+                del d_s, o
+                w = parallel.root_weight_for(t1, bts, XGMI_LINK_GBS * 1e9)
+                t = torch.tensor([w], dtype=torch.float64, device="cpu" if share else dev)
+                dist.broadcast(t, src=0)
+                root_weight = float(t.item())
+        sb, se = (parallel.shard_range_weighted(args.series, rank, world, root_weight) if root_weight != 1.0
+                  else parallel.shard_range(args.series, rank, world))
+        n_local = (se - sb) * C3_PER
+        d_xs = [c3_batch(sb, se, v) for v in range(C3_ROTATE)]
+        desc = ("BASELINE.json configs[3]: %d series x 262,144 f64 samples (%d samples over all ranks), "
+                "class = series %% 5, --compressor auto, e=1%% (max_error=(float)1/100), 256-sample frames, series "
+                "sharded contiguously by rank (%d on rank 0%s), inputs resident in HBM (%d resident batches per rank, "
+                "rotating), %s" % (args.series, units_total, se - sb,
+                                   ", root weight %.2f" % root_weight if root_weight != 1.0 else "", C3_ROTATE,
+                                   "every rank keeps its records (no collective)" if args.no_gather else
+                                   "encoded records gathered to rank 0 every step"))
+    off = np.arange(0, n_local + 1, FRAME, dtype=np.uint64)
+    plan = ctx.plan(off)
+
+    # Steady state of a compression service: batch after batch through atsc_compress_plan_dev_pipelined -- consecutive
+    # calls rotate over the plan's chains (streams of the context's own, two scratch sets each), so the kernels of
+    # batch i + 1 fill the launch gap and the drain of batch i; for N > 1 the gather of step i is issued from a side
+    # stream that waits for that step's records (atsc_plan_join).
     pipelined = not args.no_pipeline
-    ctx.set_adaptive_order(bool(args.adaptive_order))
-    NOUT = 8  # output sets: one per batch in flight (the pipelined calls rotate over up to four chains)
-    outs2 = [plan.alloc_outputs(torch, dev) for _ in range(NOUT)]
+    NOUT = 8  # output sets: one per batch in flight (up to four chains x two sets)
+    outs2 = [plan.alloc_outputs(torch, dev) for _ in range(NOUT if pipelined else 1)]
     pg = None
+    gather_on = world > 1 and not args.no_gather
     gstream = torch.cuda.Stream(device=dev) if world > 1 else None
     R = len(d_xs)
 
-    def step(i, pipe=pipelined):
-        o = outs2[i % NOUT]
-        if pg is not None:
-            pg.before_produce(i % 2)
+    def step(i, pipe=pipelined, gather=True):
+        o = outs2[i % len(outs2)]
+        slot = i % 2
+        if pg is not None and gather:
+            pg.before_produce(slot)
         plan.compress(d_xs[i % R], o, atsc_amd.AUTO, True, me, 0, stream, pipelined=pipe)
-        if world > 1:
+        if gather_on and gather:
             # the path's only exchange: the encoded records go to rank 0
             if pg is not None:
                 if pipe:
                     plan.join(gstream.cuda_stream)
                     with torch.cuda.stream(gstream):
-                        pg.submit(i % 2, o["body"], o["rec_off"][-1:])
+                        pg.submit(slot, o["body"], o["rec_off"][-1:])
                 else:
-                    pg.submit(i % 2, o["body"], o["rec_off"][-1:])
+                    pg.submit(slot, o["body"], o["rec_off"][-1:])
                 return
             if pipe:
                 plan.join(stream)
@@ -391,16 +442,16 @@ def main():
             else:
                 parallel.gather_records(dist, torch, o["body"], o["rec_off"][-1:], rank, world)
 
-    def timed_loop(steps, pipe):
+    def timed_loop(steps, pipe, gather=True):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, pipe)
+            step(i, pipe, gather)
         if pipe:
             plan.join(stream)
-        if pg is not None:
+        if pg is not None and gather:
             pg.drain()
         torch.cuda.synchronize()  # device-wide: codec, pack and communicator streams
         if world > 1:
@@ -420,27 +471,23 @@ def main():
         torch.cuda.synchronize()
         body_bytes_b.append(int(outs2[0]["rec_off"][-1].item()))
     chosen = outs2[0]["chosen"].cpu().numpy()
-    # (at least one batch through every set of every chain: a set's first batch runs in index order, without the
-    # cost hint the steady state has)
-    for i in range(max(args.warmup, 2 * NOUT if pipelined else 0, 1 if world > 1 else 0)):
-        step(i)
+    # (at least one batch through every set of every chain: the sets are built by the first call)
+    for i in range(max(args.warmup, NOUT if pipelined else 0, 1 if world > 1 else 0)):
+        step(i, gather=False)
     if pipelined:
         plan.join(stream)
     torch.cuda.synchronize()
     gather_mode = None
-    if world > 1:
+    if gather_on:
         gather_mode = "size all-gather + point-to-point sends (gather_records)"
-    if world > 1 and not share:
+    if gather_on and not share:
         # segment capacity agreed once from the warm-up result; no host sync inside the timed loop.
         # One untimed trial step validates the asynchronous gather on this backend; any exception
         # falls back to the simple size-exchange + send/recv gather (every rank takes the same branch:
         # the flag is agreed by an all-reduce).
         ok = 1
         try:
-            # (one resident batch per rank: every step encodes to the same bytes, so the agreed capacity needs no
-            # slack -- at N > 1 the step is bound by the bytes each link carries)
-            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, max(body_bytes_b),
-                                          slack=1.0 if R == 1 else 1.05)
+            pg = parallel.PipelinedGather(dist, torch, rank, world, dev, max(body_bytes_b), slack=1.05)
             step(0)
             pg.drain()
             torch.cuda.synchronize()
@@ -454,8 +501,8 @@ def main():
         if int(flag.item()) == 0:
             pg = None
         else:
-            gather_mode = "one asynchronous fixed-capacity gather per step (PipelinedGather), overlapped with the next step's codecs"
-    ctx.set_profiling(True)
+            gather_mode = ("one asynchronous fixed-capacity gather per step (PipelinedGather: capacity = the largest "
+                           "peer's records, the root's stay in place), overlapped with the next step's codecs")
     dt = timed_loop(args.steps, pipelined)
     gathered_sizes = None
     if pg is not None:
@@ -464,51 +511,51 @@ def main():
         if rank == 0:
             segs, gathered_sizes = pg.result((args.steps - 1) % 2)
             assert len(segs) == world and gathered_sizes[0] == body_bytes_b[(args.steps - 1) % R]
-    kern_ms, launches = ctx.profile_read()
-    ctx.set_profiling(False)
-    # The same steps through plain single-stream calls (atsc_compress_plan_dev: codecs, then the packing, on
-    # one stream, frames in index order, no cost hint), same rotation of batches.
+    # N > 1: the same loop without the exchange -- what the codecs alone sustain (the curve's fabric-free reading)
+    value_codec_only = None
+    gather_ms = None
+    if world > 1:
+        dt_codec = timed_loop(args.steps, pipelined, gather=False)
+        value_codec_only = units_total * args.steps / dt_codec / 1e6
+        gather_ms = max(0.0, (dt - dt_codec) / args.steps * 1e3)
+    # The same steps through plain single-stream calls (atsc_compress_plan_dev: codecs, then the packing, on the
+    # caller's stream, frames in index order), same rotation of batches.  The launches of this loop do not overlap
+    # each other: the dominant kernel's HIP events (start / stop of the dispatch itself) are taken here.
     value_no_hint = None
+    kern_ms, launches = 0.0, 0
     if world == 1:
         for i in range(2):
             step(i, False)
         torch.cuda.synchronize()
+        ctx.set_profiling(True)
         dt_plain = timed_loop(args.steps, False)
+        kern_ms, launches = ctx.profile_read()
+        ctx.set_profiling(False)
         value_no_hint = units_total * args.steps / dt_plain / 1e6
-
-    def measure_chains():
-        # The same batches dealt round-robin over CHAINS independent chains -- a context, a plan and a stream each,
-        # nothing waits across them -- as a service with several request queues would drive one GPU.  A frame kernel's
-        # workgroups are short; a single hardware queue leaves a freed slot empty for a microsecond or two before the
-        # next one starts, and several queues keep the slots fuller (tools/queue_pipe_probe.py).  Reported beside
-        # `value`, which stays the single-chain figure the `roofline` launches belong to (--chains).
-        chains = None
-        if world == 1 and args.chains:
-            CH = 4
-            cctx = [ctx] + [atsc_amd.Context(0) for _ in range(CH - 1)]
-            cplan = [plan] + [c.plan(off) for c in cctx[1:]]
-            couts = [outs2] + [[p.alloc_outputs(torch, dev), p.alloc_outputs(torch, dev)] for p in cplan[1:]]
-            cstream = [torch.cuda.Stream(device=dev) for _ in range(CH)]
-
-            def cstep(i):
-                c = i % CH
-                cplan[c].compress(d_xs[i % R], couts[c][(i // CH) % 2], atsc_amd.AUTO, True, me, 0,
-                                  cstream[c].cuda_stream, pipelined=True)
-            for i in range(8 * CH):
-                cstep(i)
+        # For continuity with rounds 1-2 (whose roofline launches ran costliest-first on a hint from a batch of the same
+        # layout): the same kernel on ONE chain with the cost order on and one resident batch -- the order is exact,
+        # i.e. what the kernel does when its drain is not the issue.  Reported beside the roofline, never as `value`.
+        ordered = None
+        if workload == "config2" and pipelined:
+            ctx.set_chains(1)
+            ctx.set_adaptive_order(True)
+            for i in range(6):
+                plan.compress(d_xs[0], outs2[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+            plan.join(stream)
             torch.cuda.synchronize()
-            ksteps = max(args.steps, 16 * CH)  # its own count: long enough for the chains' ramp and drain not to weigh
+            ctx.set_profiling(True)
             t0 = time.perf_counter()
-            for i in range(ksteps):
-                cstep(i)
+            for i in range(args.steps):
+                plan.compress(d_xs[0], outs2[i % 2], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+            plan.join(stream)
             torch.cuda.synchronize()
-            dt_ch = time.perf_counter() - t0
-            chains = {"chains": CH, "value": units_total * ksteps / dt_ch / 1e6, "unit": "Msamples/s", "steps": ksteps,
-                      "ms_per_step": dt_ch * 1e3 / ksteps,
-                      "note": "batches round-robin over %d independent (context, plan, stream) chains on one GPU; each "
-                              "chain is the pipelined path `value` times on one" % CH}
-            del cplan, couts, cctx
-        return chains
+            dt_o = time.perf_counter() - t0
+            km, kl = ctx.profile_read()
+            ctx.set_profiling(False)
+            ctx.set_adaptive_order(bool(args.adaptive_order))
+            ctx.set_chains(args.chains if args.chains else 2)
+            ordered = {"kernel_ms_avg": km / max(kl, 1), "launches": kl, "ms_per_step": dt_o / args.steps * 1e3,
+                       "note": "one chain, cost order from the SAME resident batch (exact hint), as rounds 1-2 measured it"}
 
     # BASELINE.json configs[4] beside it: every rank decodes the records it encoded, device resident (the frame
     # table of the records is parsed once, untimed: atsc_dplan_create); no exchange of any kind on this path.
@@ -553,13 +600,15 @@ def main():
 
     body_bytes = float(np.mean(body_bytes_b))
     if world > 1:
-        t = torch.tensor([body_bytes_b[0]], dtype=torch.int64, device="cpu" if share else dev)
+        t = torch.tensor([body_bytes_b[0], n_local], dtype=torch.int64, device="cpu" if share else dev)
         lst = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(lst, t)
-        per_rank_bytes = [int(v.item()) for v in lst]
+        per_rank_bytes = [int(v[0].item()) for v in lst]
+        per_rank_samples = [int(v[1].item()) for v in lst]
         total_body = float(sum(per_rank_bytes))
     else:
         per_rank_bytes = [int(body_bytes_b[0])]
+        per_rank_samples = [n_local]
         total_body = body_bytes
 
     if rank == 0:
@@ -592,17 +641,30 @@ def main():
                 "codecs_rank0": codecs,
                 "encoded_bytes_rank0": int(body_bytes),
                 "encoded_bytes_per_rank": per_rank_bytes,
-                "parallelism": ("frames sharded by rank over %d processes, backend %s (%d ranks in the group), records "
-                                "gathered to rank 0: %s" % (world, backend, dist.get_world_size(), gather_mode))
+                "samples_per_rank": per_rank_samples,
+                "parallelism": ("frames sharded by rank over %d processes, backend %s (%d ranks in the process group), %s"
+                                % (world, backend, dist.get_world_size(),
+                                   "no collective: every rank keeps its records" if args.no_gather else
+                                   "records gathered to rank 0: %s" % gather_mode))
                                if world > 1 else "single GPU",
                 "gathered_bytes_last_step": gathered_sizes,
-                "pipeline": ("record packing of step i on the pack stream overlaps the codecs of step i+1 "
-                             "(two scratch + output sets)" +
-                             ("" if not args.adaptive_order else "; within a launch the frames start costliest "
-                              "first, cost = shader clocks the same frame slot took two steps earlier (another batch)"))
-                            if pipelined else "single stream",
+                "pipeline": ("atsc_compress_plan_dev_pipelined: consecutive batches rotate over %s chains (streams of the "
+                             "context's own, two scratch sets each); frames start in %s"
+                             % (args.chains or "the default 2",
+                                "index order (no cost hint)" if not args.adaptive_order else
+                                "cost order (clocks of the same slot in an earlier batch of the chain -- a batch with "
+                                "another class layout)"))
+                            if pipelined else "single stream, plain calls",
             },
-            "roofline": {
+        }
+        if world > 1:
+            out["value_codec_only"] = value_codec_only
+            out["gather_ms_per_step"] = gather_ms
+            out["root_weight"] = root_weight
+            out["note_scaling"] = ("value = all ranks' samples / max-over-ranks time with the gather inside the timed region; "
+                                   "value_codec_only = the same loop without the exchange")
+        if world == 1:
+            out["roofline"] = {
                 "bound": "hbm",
                 "kernel": "k_compress<1,5,false,256>",
                 "achieved": achieved,
@@ -610,17 +672,27 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
+                "traffic_source": "profiles/r03_pmc.json (FETCH_SIZE / WRITE_SIZE come from separate rocprofv3 --pmc passes, "
+                                  "not from this run)",
                 "kernel_ms_avg": k_avg_ms,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
-            },
-        }
+                "note": "launch durations from the plain single-stream loop of this run (value_no_hint: frames in index order, "
+                        "no overlap between launches); the launches of the chained loop behind `value` overlap each other, so "
+                        "their individual durations say nothing about the kernel -- per step that loop moves the same bytes in "
+                        "ms_per_step, see `effective`",
+                "effective": {"achieved": algo_bytes / (dt / args.steps) / 1e9, "frac": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                              "note": "algorithmic bytes per step / ms_per_step of the chained loop"},
+            }
+            if ordered is not None:
+                out["roofline"]["cost_ordered"] = dict(ordered, achieved=algo_bytes / (ordered["kernel_ms_avg"] * 1e-3) / 1e9,
+                                                       frac=algo_bytes / (ordered["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
         if decomp is not None:
             out["decompress"] = decomp
         if value_no_hint is not None:
             out["value_no_hint"] = value_no_hint
         vmod = os.path.join(ROOT, "profiles", "valu_model.json")
-        if os.path.exists(vmod) and workload == "config2":
+        if os.path.exists(vmod) and workload == "config2" and world == 1:
             try:
                 vm = json.load(open(vmod))
                 floor_ms = float(vm["issue_floor_us_per_launch"]) * 1e-3
@@ -631,9 +703,7 @@ def main():
                 }
             except Exception:
                 pass
-        if world == 1 and args.chains:
-            out["value_chains"] = measure_chains()
-        if world == 1 and workload == "config2" and not args.no_end_to_end and not args.chains:
+        if world == 1 and workload == "config2" and not args.no_end_to_end:
             out["chunker_framing"] = chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream)
             out["end_to_end"] = end_to_end(ctx, atsc_amd, xs[0], off, me)
         if world == 1 and workload == "config2" and not args.no_cpu_baseline:

@@ -76,6 +76,18 @@ int atsc_ctx_create(atsc_ctx **out, int device);
  * before the context. */
 void atsc_ctx_destroy(atsc_ctx *ctx);
 const char *atsc_ctx_last_error(const atsc_ctx *ctx);
+/* What the library keeps between calls, and how to give it back.  A context keeps freed device blocks in a
+ * pool (up to 8 GiB) and, for the host-pointer entry points, up to four plans by frame layout with their
+ * scratch sets, workspaces and tables; the process keeps the host block the caller released last through
+ * atsc_free (decoded results; up to 2 GiB, ATSC_BIG_KEEP_MAX overrides) and the twiddle tables by
+ * transform length (up to 128 MB).  atsc_ctx_trim frees the context's share (it synchronises the
+ * device; plans the caller created stay valid), atsc_release_caches the process-wide caches. */
+int atsc_ctx_trim(atsc_ctx *ctx);
+void atsc_release_caches(void);
+/* Page-locks / releases caller memory (hipHostRegister): host-pointer calls on registered buffers copy at
+ * the link's rate, asynchronously.  The reference's caller owns its chunk (data.rs:56-76); so does this one. */
+int atsc_host_register(void *p, uint64_t bytes);
+int atsc_host_unregister(void *p);
 
 /* ------------------------------------------------------------------------ */
 /* compress: CompressorFrame::{compress, compress_bounded, compress_best}    */
@@ -192,6 +204,11 @@ int atsc_compress_frames(atsc_ctx *ctx, const double *samples, const uint64_t *f
  * atsc_compress_frames_sharded: each shard runs on its own host thread, and the outputs are byte for
  * byte those of atsc_compress_frames on one context. */
 void atsc_shard_range(uint64_t n_units, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
+/* The same split with rank 0 carrying root_weight_milli / 1000 times a peer's share: when the records are
+ * gathered to rank 0, every peer's bytes cross one link while the root's stay, so the root can take more
+ * frames (1000 = atsc_shard_range up to rounding). */
+void atsc_shard_range_weighted(uint64_t n_units, uint32_t rank, uint32_t world, uint32_t root_weight_milli,
+                               uint64_t *begin, uint64_t *end);
 int atsc_compress_frames_sharded(atsc_ctx *const *ctxs, uint32_t n_ctx, const double *samples,
                                  const uint64_t *frame_off, uint64_t n_frames, int compressor, int bounded,
                                  float max_error, int sample_level, uint8_t *body, uint64_t body_cap,

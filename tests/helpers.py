@@ -123,16 +123,17 @@ def _uniform(seed, count):
     return (_splitmix_stream(seed, count) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
 
 
-def synth_series(series_id, n, klass=None, block=65536):
-    """Series `series_id`, n samples.  klass None => class = (i // block) % 5 (single-series
-    configs); else fixed class.  One uniform draw is consumed per sample index for every class so
+def synth_series(series_id, n, klass=None, block=65536, class_shift=0):
+    """Series `series_id`, n samples.  klass None => class = (i // block + class_shift) % 5 (single-series
+    configs; class_shift moves the block -> class mapping, bench.py uses it to give every resident batch
+    another layout); else fixed class.  One uniform draw is consumed per sample index for every class so
     the stream position is a function of i alone."""
     seed = (0xA75C000000000000 + series_id) & MASK64
     i = np.arange(n, dtype=np.float64)
     u = _uniform(seed, n)
     out = np.empty(n, dtype=np.float64)
     if klass is None:
-        cls = (np.arange(n) // block) % 5
+        cls = (np.arange(n) // block + class_shift) % 5
     else:
         cls = np.full(n, klass)
     two_pi = 2.0 * math.pi

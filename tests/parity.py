@@ -129,7 +129,8 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
     nf = len(off) - 1
     assert len(frames) == nf
     assert int(rec_off[-1]) == len(rec)
-    summary = {"exact": 0, "tol": 0, "tie": 0, "boundary": 0, "fail": [], "codecs": {}, "bytes": len(rec),
+    summary = {"exact": 0, "tol": 0, "tie": 0, "boundary": 0, "tie_frames": [], "boundary_frames": [], "fail": [], "codecs": {},
+               "bytes": len(rec),
                "oracle_bytes": 0, "records": rec, "chosen": chosen, "err": err}
     for i, (fs, sc, tag, payload) in enumerate(frames):
         fx = x[int(off[i]):int(off[i + 1])]
@@ -152,8 +153,18 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
             summary["fail"].append((i, verdict))
         elif verdict == "tie":
             summary["tie"] += 1
+            summary["tie_frames"].append(i)
+            # A tied frame admitted another bin of (near-)equal norm somewhere: its reconstruction differs by that
+            # bin pair's contribution, not by more.  When both ladders stopped at the same K the reported errors are
+            # still held together, with the tolerance widened by the decode bar's full noise term (TIE_ERR_FACTOR x).
+            if tag == oracle.FFT and chosen_same_k(payload, po):
+                tol = TIE_ERR_FACTOR * (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo) + fft_err_noise(fx))
+                if not (abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
+                    summary["fail"].append((i, "FAIL:err of a tie frame gpu=%r oracle=%r tol=%r" % (err[i], eo, tol)))
         else:
             summary[verdict] += 1
+            if verdict == "boundary":
+                summary["boundary_frames"].append(i)
             if verdict != "boundary":
                 # reported error: exact codecs report 0.0; lossy within tolerance
                 tol = (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo) + fft_err_noise(fx)) if tag == oracle.FFT \
@@ -161,6 +172,16 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
                 if not (err[i] == eo or abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
                     summary["fail"].append((i, "FAIL:err gpu=%r oracle=%r" % (err[i], eo)))
     return summary
+
+
+TIE_ERR_FACTOR = 8.0
+
+
+def chosen_same_k(payload, payload_o):
+    try:
+        return len(H.parse_fft_payload(payload)[0]) == len(H.parse_fft_payload(payload_o)[0])
+    except Exception:
+        return False
 
 
 def H_varint(v):
@@ -173,11 +194,21 @@ def H_varint(v):
     return bytes([253]) + int(v).to_bytes(8, "little")
 
 
-def assert_summary(summary, nf, what=""):
-    msg = "%s: %d frames exact=%d tol=%d tie=%d boundary=%d fail=%d %s" % (
-        what, nf, summary["exact"], summary["tol"], summary.get("tie", 0), summary["boundary"],
-        len(summary["fail"]), summary["fail"][:8])
+def assert_summary(summary, nf, what="", allow_tie=(), allow_boundary=()):
+    """Every frame compared, none failed; `tie` and `boundary` verdicts (which skip part of the comparison) are capped:
+    batches of 500 frames and more at TIE_FRAC / BOUNDARY_FRAC of the batch, smaller ones at ONE tie and NO boundary
+    frame -- unless the test names the frames it expects there (allow_tie / allow_boundary: frame indices).  A
+    one-frame batch therefore passes only with verdict exact or tol."""
+    msg = "%s: %d frames exact=%d tol=%d tie=%d %s boundary=%d %s fail=%d %s" % (
+        what, nf, summary["exact"], summary["tol"], summary.get("tie", 0), summary.get("tie_frames", [])[:8],
+        summary["boundary"], summary.get("boundary_frames", [])[:8], len(summary["fail"]), summary["fail"][:8])
     assert not summary["fail"], msg
-    assert summary["boundary"] <= max(1, int(BOUNDARY_FRAC * nf)), msg
-    assert summary.get("tie", 0) <= max(2, int(TIE_FRAC * nf)), msg
+    ties = [i for i in summary.get("tie_frames", []) if i not in allow_tie]
+    bounds = [i for i in summary.get("boundary_frames", []) if i not in allow_boundary]
+    if nf >= 500:
+        assert len(bounds) <= int(BOUNDARY_FRAC * nf), msg
+        assert len(ties) <= int(TIE_FRAC * nf), msg
+    else:
+        assert len(bounds) == 0, msg
+        assert len(ties) <= (1 if nf > 1 else 0), msg
     return msg

@@ -168,6 +168,87 @@ def test_gather_records_gloo(world, n_frames):
     assert len(sizes) == world and sum(sizes) == len(got)
 
 
+def _uneven_worker(rank, world, port, q):
+    """Root-heavy shards (shard_range_weighted) through the steady-state gather: the capacity is the largest
+    PEER's size, the root's own (larger) records never travel, and the stream is the frames in order."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from atsc_amd import parallel as P
+
+    n_frames = 1000
+    b, e = P.shard_range_weighted(n_frames, rank, world, 1.6)
+    rec = _fake_records(range(b, e))
+    pg = P.PipelinedGather(dist, torch, rank, world, torch.device("cpu"), len(rec), slack=1.0)
+    sizes_all = [None] * world
+    dist.all_gather_object(sizes_all, len(rec))
+    assert pg.room == ((max(sizes_all[1:]) + 4096 + 8 + 15) & ~15) - 8, (pg.room, sizes_all)  # the peers' sizes alone
+    bufs = [torch.zeros(len(rec) + 64, dtype=torch.uint8) for _ in range(2)]
+    for i in range(3):
+        pg.before_produce(i % 2)
+        bufs[i % 2][: len(rec)] = torch.frombuffer(bytearray(rec), dtype=torch.uint8)
+        pg.submit(i % 2, bufs[i % 2], torch.tensor([len(rec)], dtype=torch.int64))
+    pg.drain()
+    assert not pg.overflowed()
+    if rank == 0:
+        segs, sizes = pg.result(0)
+        q.put((b"".join(bytes(s.numpy().tobytes()) for s in segs), sizes, (b, e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_gather_root_heavy_shards(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, sizes, root = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == _fake_records(range(1000)) and sum(sizes) == len(got)
+    assert root[1] - root[0] > 1000 // world  # the root's shard is the largest
+
+
+def test_shard_range_weighted_partitions():
+    sys.path.insert(0, ROOT)
+    from atsc_amd import parallel as P
+
+    import ctypes as C
+
+    import __graft_entry__ as G
+
+    G.build()
+    from atsc_amd import capi
+
+    for n in (1, 7, 64, 4096, 40960, 4194304):
+        for world in (1, 2, 3, 8):
+            for w in (1.0, 1.51, 2.2, 0.5):
+                parts = [P.shard_range_weighted(n, r, world, w) for r in range(world)]
+                for r in range(world):  # the C ABI cuts at the same frames
+                    b, e = C.c_uint64(), C.c_uint64()
+                    capi.lib().atsc_shard_range_weighted(n, r, world, int(round(w * 1000)), C.byref(b), C.byref(e))
+                    assert (b.value, e.value) == parts[r], (n, world, w, r)
+                assert parts[0][0] == 0 and parts[-1][1] == n
+                for a, b in zip(parts, parts[1:]):
+                    assert a[1] == b[0]
+                if world > 1 and n >= 1000:
+                    sz = [e - b for b, e in parts]
+                    peers = sz[1:]
+                    assert max(peers) - min(peers) <= 1
+                    assert abs(sz[0] / max(1.0, sum(peers) / len(peers)) - w) < 0.02 * w + 0.01
+    # the model of DESIGN.md section 5: configs[3] on 8 GPUs
+    w = P.root_weight_for(17.9e-3, 1.9e9, 70e9)
+    assert 1.45 < w < 1.58  # (B / R) / T1 = 27.1 ms / 17.9 ms
+    b0, e0 = P.shard_range_weighted(4096, 0, 8, w)
+    b1, e1 = P.shard_range_weighted(4096, 1, 8, w)
+    assert (e0 - b0) > (e1 - b1)
+
+
 def test_shard_range_partitions():
     sys.path.insert(0, ROOT)
     from atsc_amd import parallel as P

@@ -622,6 +622,50 @@ def test_pipelined_batches_match_plain_calls(ctx, A):
     plan.close() if hasattr(plan, "close") else None
 
 
+@pytest.mark.parametrize("F,nf,chains", [(131072, 12, 2), (256, 4096, 4), (131072, 12, 1)])
+def test_pipelined_input_release_lets_the_caller_refill_one_buffer(ctx, A, F, nf, chains):
+    """The kernels of a pipelined call read d_samples on the context's streams, not in the caller's stream order
+    (include/atsc_hip.h): a caller that keeps ONE input buffer and refills it batch after batch orders every refill
+    behind atsc_plan_input_release.  Six batches through one buffer -- large frames (the fast path's kernels, on two
+    chains or one) and small ones (four chains) -- give the bytes of plain calls on private buffers."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    off = H.frame_offsets(nf * F, F)
+    ctx.set_chains(chains)
+    try:
+        plan = ctx.plan(off)
+        side = torch.cuda.Stream(device=dev)  # the caller's stream: refills and calls are enqueued here
+        batches = [torch.from_numpy(H.synth_series(300 + b, nf * F, class_shift=b)).to(dev) for b in range(6)]
+
+        def fetch(o):
+            total = int(o["rec_off"][-1].item())
+            return o["body"][:total].cpu().numpy().tobytes()
+
+        o = plan.alloc_outputs(torch, dev)
+        ref = []
+        for d_x in batches:
+            plan.compress(d_x, o, A.AUTO, True, ME5, 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ref.append(fetch(o))
+        assert len(set(ref)) == len(ref)
+        buf = torch.empty(nf * F, dtype=torch.float64, device=dev)
+        outs = [plan.alloc_outputs(torch, dev) for _ in batches]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for b, d_x in enumerate(batches):
+                plan.input_release(side.cuda_stream)  # the refill below waits for the previous calls' last read
+                buf.copy_(d_x, non_blocking=True)
+                plan.compress(buf, outs[b], A.AUTO, True, ME5, 0, side.cuda_stream, pipelined=True)
+            plan.join(side.cuda_stream)
+        side.synchronize()
+        for b in range(len(batches)):
+            assert fetch(outs[b]) == ref[b], "batch %d differs (F=%d, %d chains)" % (b, F, chains)
+        plan.close()
+    finally:
+        ctx.set_chains(2)
+
+
 # ---------------------------------------------------------------------------------------
 # forced Idw on large frames (polynomial.rs:375-393 at 4097 .. 131072 samples)
 # ---------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ def _compress_dev(torch, A, ctx, x, frame, me):
     return rec, nb, chosen
 
 
-def _rank_main(rank, world, port, frame, path):
+def _rank_main(rank, world, port, frame, path, root_weight=1.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -64,7 +64,8 @@ def _rank_main(rank, world, port, frame, path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = A.Context(0)
-    s0, s1 = P.shard_range(SERIES, rank, world)  # whole series per rank: SURVEY 8(d) config 4
+    # whole series per rank: SURVEY 8(d) config 4; root_weight != 1: the root-heavy split (rank 0 takes more series)
+    s0, s1 = P.shard_range_weighted(SERIES, rank, world, root_weight) if root_weight != 1.0 else P.shard_range(SERIES, rank, world)
     x = _series_block(s0, s1)
     rec, nb, _ = _compress_dev(torch, A, ctx, x, frame, ME1)
     out, sizes = P.gather_records(dist, torch, rec, nb, rank, world)
@@ -78,8 +79,9 @@ def _rank_main(rank, world, port, frame, path):
     ctx.close()
 
 
-@pytest.mark.parametrize("frame", [256, 131072])
-def test_sharded_stream_is_the_single_process_stream(frame, tmp_path):
+@pytest.mark.parametrize("frame,root_weight", [(256, 1.0), (131072, 1.0), (256, 1.51), (131072, 2.2)])
+def test_sharded_stream_is_the_single_process_stream(frame, root_weight, tmp_path):
+    """(root_weight != 1: uneven shards -- the root-heavy split of DESIGN.md section 5 -- give the same bytes)"""
     import torch
     import torch.multiprocessing as mp
 
@@ -87,7 +89,7 @@ def test_sharded_stream_is_the_single_process_stream(frame, tmp_path):
     path = str(tmp_path / ("gathered_%d.bin" % frame))
     mpc = mp.get_context("spawn")
     port = _free_port()
-    procs = [mpc.Process(target=_rank_main, args=(r, world, port, frame, path)) for r in range(world)]
+    procs = [mpc.Process(target=_rank_main, args=(r, world, port, frame, path, root_weight)) for r in range(world)]
     for p in procs:
         p.start()
     # meanwhile, the same batch in this process on one context
@@ -106,6 +108,11 @@ def test_sharded_stream_is_the_single_process_stream(frame, tmp_path):
     gathered = open(path, "rb").read()
     sizes = [int(v) for v in open(path + ".sizes").read().split()]
     assert len(sizes) == world and all(s > 0 for s in sizes) and sum(sizes) == len(gathered)
+    if root_weight != 1.0:
+        from atsc_amd import parallel as P
+
+        b0, e0 = P.shard_range_weighted(SERIES, 0, world, root_weight)
+        assert e0 - b0 > SERIES - (e0 - b0), "the root carries the larger shard"
     assert gathered == single, "sharded + gathered records differ from the single-process stream"
     # the gathered bytes are a well-formed stream of the right frames and decode to the same samples
     nf = len(x) // frame
@@ -120,8 +127,8 @@ def test_sharded_stream_is_the_single_process_stream(frame, tmp_path):
     assert np.array_equal(aa[lossless], xa[lossless])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity.log"), "a") as f:
-        f.write("sharded stream (2 processes, frame %d): %d frames, %d bytes (%s per rank), identical to the "
-                "single-process stream; codecs %s\n" % (frame, nf, len(gathered), sizes,
+        f.write("sharded stream (2 processes, frame %d, root weight %.2f): %d frames, %d bytes (%s per rank), identical to the "
+                "single-process stream; codecs %s\n" % (frame, root_weight, nf, len(gathered), sizes,
                                                         {int(c): int(np.sum(chosen == c)) for c in np.unique(chosen)}))
     ctx.close()
 
