@@ -2053,6 +2053,23 @@ __global__ __launch_bounds__(LT) void k_compress_large(
                 uint32_t K = used;
                 if (!resume) {
                 K = min(P.mf + jump, Z);
+                // The ladder whose next payload is the smaller goes first.  A polynomial that is still climbing runs its
+                // trips while they store less than this FFT trip would: once it passes, the FFT ladder is pruned by its
+                // size -- left to itself it walks up to 23 trips (0.8 ms each at the far end) that cannot win (a frame
+                // half ramp, half gauge at e = 1 %: 18.9 ms).  Pruning only skips candidates that cannot win: the
+                // selection is unchanged.
+                if (prune && fft_trips >= 1 && run_poly && poly_active && !idw) {
+                    auto poly_next_lb = [&]() -> uint32_t {
+                        const uint32_t base = (3 >= n / 100) ? 3 : n / 100;
+                        const uint32_t pts = base + pjump;
+                        const uint32_t step = max(n / pts, 1u);
+                        const uint32_t cnt = (n + step - 1) / step;
+                        const uint32_t Kp = cnt + (((cnt - 1) * step != n - 1) ? 1u : 0u);
+                        return 2 + vlen(Kp) + Kp * (bitdepth == 0 ? 8u : 1u) + 17;
+                    };
+                    while (poly_active && poly_next_lb() <= 1 + vlen(K) + 9 * K + 8) poly_ladder(1);
+                    if (!poly_active) poly_finish();
+                }
                 // (same prefix, longer: first the two trips most frames need, then five, then everything)
                 if (K > nkeys && nkeys < min(kcap_total, bins))
                     nkeys = build_order(nkeys < 4096u ? min(kcap_total, max(4096u, P.mf + 4 * P.dk1)) : kcap_total);
