@@ -672,6 +672,8 @@ struct PreFrame {
 };
 DEVI const double *frame_samples(const double *samples, const DevFrame &fr) { return samples + fr.sample_off; }
 DEVI const double *frame_samples(const double *, const DevDFrame &) { return nullptr; }  // decoder: no samples
+DEVI double *frame_out(double *, const DevFrame &) { return nullptr; }                  // encoder: no decoded output
+DEVI double *frame_out(double *outp, const DevDFrame &fr) { return outp + fr.out_off; }
 template <class FR>
 DEVI PreFrame pre_frame(const double *samples, const FR *frames, const uint32_t *ids,
                         const DevPlan *plans, unsigned char *ws_base, uint64_t ws_stride, const DevPlan *&P)
@@ -2436,6 +2438,7 @@ __global__ __launch_bounds__(LT) void k_large_trip_tiles(
     if (tid == 0) ((double *)(Cb + TRIP_PARTIAL_OFF))[blockIdx.y] = s;
 }
 
+constexpr uint32_t STG_BYTES = 16384;  // payload window of the large decoder (RdS, atsc_device.h)
 #include "atsc_large_fast.h"
 
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
@@ -2484,7 +2487,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     if (fast) {
         e = ensure_dyn_lds((const void *)k_large_decide1, FAST_D1_LDS);
         if (e != hipSuccess) return e;
-        e = ensure_dyn_lds((const void *)k_large_trip243, FAST_TILE_LDS);
+        e = ensure_dyn_lds((const void *)k_large_trip243<false, DevFrame>, FAST_TILE_LDS);
         if (e != hipSuccess) return e;
         e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
         if (e != hipSuccess) return e;
@@ -2519,8 +2522,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             }
             hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), FAST_D1_LDS, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, ws, ws_stride);
-            hipLaunchKernelGGL(k_large_trip243, dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s, samples, frames,
-                               ids + b0, plans, twpool, ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0);
+            hipLaunchKernelGGL((k_large_trip243<false, DevFrame>), dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s, samples,
+                               frames, ids + b0, plans, twpool, ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
             hipLaunchKernelGGL(k_large_decide2, dim3(nb), dim3(LT), FAST_D2_LDS, s, samples, frames, ids + b0, plans, kp,
                                slots, res, ws, ws_stride);
             // whatever those left undecided (FastState::status != 2)
@@ -2577,7 +2580,6 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
 // --------------------------------------------------------------------------------------------
 // k_decompress_large: CompressorFrame::decompress for frames of 4097 .. 131072 samples
 // --------------------------------------------------------------------------------------------
-constexpr uint32_t STG_BYTES = 16384;  // payload window of the large decoder (RdS, atsc_device.h)
 
 // PH 0: the whole decoder.  PH 1 / PH 2: the decoder around the batched inverse transform -- PH 1 parses,
 // decodes every codec but FFT completely and leaves an FFT frame's conjugated packed spectrum in buffer A
@@ -2588,7 +2590,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
     const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
-    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse, int sp_split)
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse, int sp_split, int fast_skip)
 {
     constexpr int T = LT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2643,6 +2645,8 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
         return;
     }
     if ((PH == 1 || (PH == 0 && sp_split)) && tid == 0) pend->pending = 0;
+    // behind the decoder's fast path (k_large_dparse + k_large_trip243<true>): only the frames it left alone
+    if (PH == 0 && fast_skip && ((const FastState *)(ws + lay.o_front))->status != 0) return;
 
     // fixed-width point arrays (U8 / F64) are read in parallel after the header; the spectrum must be
     // empty before lane 0 starts filling it
@@ -3092,19 +3096,34 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             // parse + every codec but the FFT transform; the transform of all pending frames over the whole
             // GPU; scale / round / clamp
             hipLaunchKernelGGL(k_decompress_large<1>, dim3(nb), dim3(LT), 256 + STG_BYTES, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse, 0);
+                               body, out, status, ws, ws_stride, tiled, sparse, 0, 0);
             hipLaunchKernelGGL((k_large_pre1<DevDFrame, true>), dim3(pre->tiles1, nb), dim3(PT), lds1, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL((k_large_pre2<DevDFrame, true>), dim3(pre->tiles2, nb), dim3(PT), lds2, s,
                                (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride);
             hipLaunchKernelGGL(k_decompress_large<2>, dim3(nb), dim3(LT), 256, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse, 0);
+                               body, out, status, ws, ws_stride, tiled, sparse, 0, 0);
         } else {
             // (with every CU busy on its own frame the grid only repeats the table loads per tile: e = 1 %,
             // 512 frames: 1.53 vs 1.12 ms)
             const int sp_split = (sparse && sp_tiles && count <= LARGE_SPLIT_MAX) ? 1 : 0;
+            // FFT frames of 131072 samples: k_large_dparse + the tile grid (atsc_large_fast.h); the rest, and whatever
+            // the parser leaves alone, behind them
+            static const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;
+            const int fast = (!no_fast && sparse && pre && pre->cols243 && pre->rows9p == 32) ? 1 : 0;
+            if (fast) {
+                e = ensure_dyn_lds((const void *)k_large_dparse, FAST_DP_LDS);
+                if (e != hipSuccess) return e;
+                e = ensure_dyn_lds((const void *)k_large_trip243<true, DevDFrame>, FAST_TILE_LDS);
+                if (e != hipSuccess) return e;
+                static const int dbg = getenv("ATSC_DEBUG_DPARSE") ? 1 : 0;
+                hipLaunchKernelGGL(k_large_dparse, dim3(nb), dim3(LT), FAST_DP_LDS, s, frames, ids + b0, plans, twpool, body,
+                                   ws, ws_stride, dbg);
+                hipLaunchKernelGGL((k_large_trip243<true, DevDFrame>), dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s,
+                                   (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride, 0, out);
+            }
             hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse, sp_split);
+                               body, out, status, ws, ws_stride, tiled, sparse, sp_split, fast);
             if (sp_split)
                 hipLaunchKernelGGL(k_decompress_large_tiles, dim3((nb + 7u) & ~7u, sp_tiles), dim3(LT), SP_LDS_BYTES, s,
                                    frames, ids + b0, plans, twpool, out, ws, ws_stride, nb);

@@ -68,6 +68,124 @@ DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t 
     }
 }
 
+// The packed-spectrum points of a list of bins, bucketed by k mod 243 and laid out for k_large_trip243 (see
+// sparse_bucket): entry(i, p, x) gives bin position p (< M) and value x of list entry i, false if the entry is void.
+// K <= 2 LT entries.  LDS: zl / zs two regions of 2 K SpEnt each, tab 1024 u32.  Leaves the list, the bucket bounds and
+// the buckets' order by size in buffer B; returns the number of points.  Every bucket ends up in ascending (kb, kind)
+// order -- the f32 sums of the tiles do not depend on the order the atomics happened to serve -- by counting: a
+// point's place is the number of smaller keys in its bucket (keys are distinct), one thread per point.  (An insertion
+// sort by one thread per bucket took 70 us on frames whose bins sit on few residues: a signal of period 64 puts every
+// harmonic on a multiple of L / 64 = 9 * 243.)
+template <class EntryFn>
+DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t M, SpEnt *zl, SpEnt *zs, uint32_t *tab,
+                          uint32_t *bcw, unsigned char *Bb)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t *beg = tab, *end = tab + 256, *cnt = tab + 512, *border = tab + 768;
+    for (uint32_t e = tid; e < 256; e += LT) { beg[e] = 0; cnt[e] = 0; }
+    __syncthreads();
+    auto points = [&](uint32_t i, uint32_t (&kk)[2], float2 (&vv)[2]) -> uint32_t {
+        uint32_t p;
+        float2 x;
+        if (!entry(i, p, x)) return 0;
+        // (p < M for this class: the first point always exists; it takes slot 0, the mirror slot 1)
+        {
+            const float2 h = make_float2(0.5f * x.x, 0.5f * x.y);
+            const float2 o = cmulp(h, tw[p]);
+            kk[0] = p;
+            vv[0] = make_float2(h.x - o.y, -(h.y + o.x));
+        }
+        if (p >= 1) {
+            const float2 ee = make_float2(0.5f * x.x, -0.5f * x.y);
+            const float2 d = make_float2(-0.5f * x.x, 0.5f * x.y);
+            const float2 o = cmulp(d, tw[M - p]);
+            kk[1] = (M - p) | 0x80000000u;
+            vv[1] = make_float2(ee.x - o.y, -(ee.y + o.x));
+            return 2;
+        }
+        return 1;
+    };
+    uint32_t mykk[2][2];
+    float2 myvv[2][2];
+    uint32_t myc[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t i = tid + u * LT;
+        if (i < K) {
+            myc[u] = points(i, mykk[u], myvv[u]);
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                if (q < myc[u]) atomicAdd(&beg[(mykk[u][q] & 0x7fffffffu) % FAST_MF], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 243 bucket sizes by one wavefront (4 per lane)
+        uint32_t c[4], s = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = beg[4 * tid + u]; s += c[u]; }
+        const uint32_t incl = wave_incl_scan_u32(s);
+        uint32_t run = incl - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { beg[4 * tid + u] = run; run += c[u]; }
+        if (tid == 63) bcw[0] = incl;
+    }
+    __syncthreads();
+    const uint32_t nlist = bcw[0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            if (q >= myc[u]) continue;
+            const uint32_t k = mykk[u][q] & 0x7fffffffu;
+            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
+            const uint32_t slot = beg[ka] + atomicAdd(&cnt[ka], 1u);
+            SpEnt z;
+            z.key = (kb << 1) | (mykk[u][q] >> 31);
+            z.re = myvv[u][q].x;
+            z.im = myvv[u][q].y;
+            zl[slot] = z;
+        }
+    __syncthreads();
+    if (tid < FAST_MF) end[tid] = beg[tid] + cnt[tid];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            if (q >= myc[u]) continue;
+            const uint32_t k = mykk[u][q] & 0x7fffffffu;
+            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
+            const uint32_t key = (kb << 1) | (mykk[u][q] >> 31);
+            const uint32_t b = beg[ka], e = end[ka];
+            uint32_t rank = 0;
+            for (uint32_t t = b; t < e; ++t) rank += zl[t].key < key ? 1u : 0u;
+            SpEnt z;
+            z.key = key;
+            z.re = myvv[u][q].x;
+            z.im = myvv[u][q].y;
+            zs[b + rank] = z;
+        }
+    // the buckets by descending size (ties by index): the tiles deal them over their thread groups in this order
+    if (tid < FAST_MF) {
+        const uint32_t mine = cnt[tid];
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < FAST_MF; ++t) {
+            const uint32_t o = cnt[t];
+            rank += (o > mine || (o == mine && t < tid)) ? 1u : 0u;
+        }
+        border[rank] = tid;
+    }
+    __syncthreads();
+    {
+        uint32_t *gl = (uint32_t *)(Bb + FAST_LIST_OFF);
+        const uint32_t *src = (const uint32_t *)zs;
+        for (uint32_t w = tid; w < 3 * nlist; w += LT) gl[w] = src[w];
+        uint32_t *gb = (uint32_t *)(Bb + FAST_BOUNDS_OFF);
+        for (uint32_t e = tid; e < FAST_MF; e += LT) { gb[e] = beg[e]; gb[256 + e] = end[e]; gb[512 + e] = border[e]; }
+    }
+    return nlist;
+}
+
 __global__ __launch_bounds__(LT) void k_large_decide1(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
@@ -391,119 +509,19 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     }
     __syncthreads();
     FSTAMP(5);  // 5: admission
-    // ---- the trip's packed-spectrum points, bucketed by k mod 243 (see sparse_bucket) ----
-    // (the candidate list is done with: its LDS hosts the list)
-    SpEnt *zl = (SpEnt *)cand;                       // <= 2 K1 points of 12 bytes
-    uint32_t *beg = h2, *end = h2 + 256, *cnt = h2 + 512;
-    for (uint32_t e = tid; e < 256; e += LT) { beg[e] = 0; cnt[e] = 0; }
-    __syncthreads();
-    auto points = [&](uint32_t i, uint32_t (&kk)[2], float2 (&vv)[2]) -> uint32_t {
-        const Sel e = sel[i];
-        const uint32_t p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
-        if (p < FAST_OWN && own[p] != skey[i]) return 0;
-        const float2 x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
-        // (p <= 65535 < M for this class: the first point always exists; it takes slot 0, the mirror slot 1)
-        {
-            const float2 h = make_float2(0.5f * x.x, 0.5f * x.y);
-            const float2 o = cmulp(h, tw[p]);
-            kk[0] = p;
-            vv[0] = make_float2(h.x - o.y, -(h.y + o.x));
-        }
-        if (p >= 1) {
-            const float2 ee = make_float2(0.5f * x.x, -0.5f * x.y);
-            const float2 d = make_float2(-0.5f * x.x, 0.5f * x.y);
-            const float2 o = cmulp(d, tw[M - p]);
-            kk[1] = (M - p) | 0x80000000u;
-            vv[1] = make_float2(ee.x - o.y, -(ee.y + o.x));
-            return 2;
-        }
-        return 1;
-    };
-    uint32_t mykk[2][2];
-    float2 myvv[2][2];
-    uint32_t myc[2] = {0, 0};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {  // K1 <= FAST_K_MAX <= 2 LT
-        const uint32_t i = tid + u * LT;
-        if (i < K1) {
-            myc[u] = points(i, mykk[u], myvv[u]);
-#pragma unroll
-            for (uint32_t q = 0; q < 2; ++q)
-                if (q < myc[u]) atomicAdd(&beg[(mykk[u][q] & 0x7fffffffu) % FAST_MF], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {  // exclusive scan of the 243 bucket sizes by one wavefront (4 per lane)
-        uint32_t c[4], s = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { c[u] = beg[4 * tid + u]; s += c[u]; }
-        const uint32_t incl = wave_incl_scan_u32(s);
-        uint32_t run = incl - s;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { beg[4 * tid + u] = run; run += c[u]; }
-        if (tid == 63) bc[10] = incl;
-    }
-    __syncthreads();
-    const uint32_t nlist = bc[10];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (uint32_t q = 0; q < 2; ++q) {
-            if (q >= myc[u]) continue;
-            const uint32_t k = mykk[u][q] & 0x7fffffffu;
-            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
-            const uint32_t slot = beg[ka] + atomicAdd(&cnt[ka], 1u);
-            SpEnt z;
-            z.key = (kb << 1) | (mykk[u][q] >> 31);
-            z.re = myvv[u][q].x;
-            z.im = myvv[u][q].y;
-            zl[slot] = z;
-        }
-    __syncthreads();
-    // Every bucket in ascending (kb, kind) order -- the f32 sums of the tiles do not depend on the order the atomics
-    // happened to serve -- by counting: an entry's place is the number of smaller keys in its bucket (keys are
-    // distinct), one thread per entry.  (An insertion sort by one thread per bucket took 70 us on frames whose bins sit
-    // on few residues: a signal of period 64 puts every harmonic on a multiple of L / 64 = 9 * 243.)
-    SpEnt *zs = (SpEnt *)own;  // the owners are done with (points() ran): 32 KB of their 36 KB
-    if (tid < FAST_MF) end[tid] = beg[tid] + cnt[tid];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (uint32_t q = 0; q < 2; ++q) {
-            if (q >= myc[u]) continue;
-            const uint32_t k = mykk[u][q] & 0x7fffffffu;
-            const uint32_t kb = k / FAST_MF, ka = k - kb * FAST_MF;
-            const uint32_t key = (kb << 1) | (mykk[u][q] >> 31);
-            const uint32_t b = beg[ka], e = end[ka];
-            uint32_t rank = 0;
-            for (uint32_t t = b; t < e; ++t) rank += zl[t].key < key ? 1u : 0u;
-            SpEnt z;
-            z.key = key;
-            z.re = myvv[u][q].x;
-            z.im = myvv[u][q].y;
-            zs[b + rank] = z;
-        }
-    // the buckets by descending size (ties by index): the tiles deal them over their thread groups in this order
-    uint32_t *border = cnt + 256;  // h2[768 ..]
-    if (tid < FAST_MF) {
-        const uint32_t mine = cnt[tid];
-        uint32_t rank = 0;
-        for (uint32_t t = 0; t < FAST_MF; ++t) {
-            const uint32_t o = cnt[t];
-            rank += (o > mine || (o == mine && t < tid)) ? 1u : 0u;
-        }
-        border[rank] = tid;
-    }
-    __syncthreads();
+    // ---- the trip's packed-spectrum points, bucketed by k mod 243 ----
+    // (the candidate list and the owners are done with once the points are formed: their LDS hosts the two list buffers)
+    const uint32_t nlist = fast_bucket(
+        K1,
+        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+            const Sel e = sel[i];
+            p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
+            if (p < FAST_OWN && own[p] != skey[i]) return false;
+            x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
+            return true;
+        },
+        tw, M, (SpEnt *)cand, (SpEnt *)own, h2, bc + 10, Bb);  // (own[] is read by entry() before zs is first written)
     FSTAMP(6);  // 6: bucketing
-    {
-        uint32_t *gl = (uint32_t *)(Bb + FAST_LIST_OFF);
-        const uint32_t *src = (const uint32_t *)zs;
-        for (uint32_t w = tid; w < 3 * nlist; w += LT) gl[w] = src[w];
-        uint32_t *gb = (uint32_t *)(Bb + FAST_BOUNDS_OFF);
-        for (uint32_t e = tid; e < FAST_MF; e += LT) { gb[e] = beg[e]; gb[256 + e] = end[e]; gb[512 + e] = border[e]; }
-    }
     if (tid == 0) {
         FastState f;
         f.status = 1;
@@ -523,25 +541,106 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
 // One tile (16 output columns jb) of the first FFT trip of one frame: F[288 ja + jb] for every ja, compared with the
 // padded samples 2 j, 2 j + 1 (j = 288 ja + jb); the tile's share of the MAPE sum goes to buffer C.
 // Thread (column c, q): inputs ka = 9 a + q of its column straight from the buckets, then as k_large_cols243.
+// DECODE: the same tile for k_large_dparse's list, writing the frame's decoded samples (fft.rs:426-462) instead of an
+// error sum: FR = DevDFrame, io = the output buffer.
+template <bool DECODE, class FR>
 __global__ __launch_bounds__(CT) void k_large_trip243(
-    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const double *__restrict__ samples, const FR *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base,
-    uint64_t ws_stride, int dbg)
+    uint64_t ws_stride, int dbg, double *__restrict__ outp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
 #define TSTAMP(i) do { if (dbg) tstamp[i] = wall_clock64(); } while (0)
     TSTAMP(0);
-    const DevFrame fr = frames[ids[blockIdx.y]];
+    const FR fr = frames[ids[blockIdx.y]];
     const DevPlan &P = plans[fr.plan];
     unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
     const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
     const FastState *fs = (const FastState *)(ws + lay.o_front);
+    if constexpr (DECODE) {
+        if (fs->status == 3) {
+            // A polynomial frame k_large_dparse prepared: this workgroup evaluates piece blockIdx.x of FAST_TILES
+            // (polynomial.rs:342-373 with the encoder's tables -- tangents per segment, Hermite basis per in-segment
+            // offset, exact r / step -- bit for bit the general decoder's values).
+            const uint32_t n = P.n;
+            const uint32_t K = fs->poly_K, step = fs->poly_step;
+            const double mn = fs->smin, mx = fs->smax;
+            const double *vals = (const double *)(ws + lay.o_tab);
+            double *out = frame_out(outp, fr);
+            double4 *hbt = (double4 *)smem;                 // step <= 255 entries
+            double2 *mms = (double2 *)(smem + 8192);        // segments of this piece
+            const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / FAST_TILES);
+            const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / FAST_TILES);
+            const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
+            const uint32_t gapL = (n - 1) - (K - 2) * step;
+            const double stepd = (double)step, gapLd = (double)gapL;
+            const double ry = 1.0 / stepd, ryL = 1.0 / gapLd;
+            uint32_t sgA = __umulhi(i0, magic), sgB = __umulhi(i1 - 1, magic);
+            if (sgA > K - 2) sgA = K - 2;
+            if (sgB > K - 2) sgB = K - 2;
+            if (sgB - sgA + 1 > 1536) return;  // (step >= 16: at most n / 18 / 16 + 2 segments)
+            for (uint32_t sg = sgA + tid; sg <= sgB; sg += CT) {
+                double2 t = make_double2(0.0, 0.0);
+                if (sg >= 1 && sg + 2 < K) {
+                    const uint32_t t0i = sg * step;
+                    const uint32_t t1i = (sg + 1 == K - 1) ? (n - 1) : (sg + 1) * step;
+                    const uint32_t tmi = (sg - 1) * step;
+                    const uint32_t tpi = (sg + 2 == K - 1) ? (n - 1) : (sg + 2) * step;
+                    const double t0 = (double)t0i, t1 = (double)t1i;
+                    const double v0 = vals[sg], v1 = vals[sg + 1], vm = vals[sg - 1], vp = vals[sg + 2];
+                    t.x = (v1 - vm) / (t1 - (double)tmi) * (t1 - t0);
+                    t.y = (vp - v0) / ((double)tpi - t0) * (t1 - t0);
+                }
+                mms[sg - sgA] = t;
+            }
+            for (uint32_t r = tid; r < step; r += CT) {
+                const double nt = div_small((double)r, stepd, ry);
+                const double t2 = nt * nt;
+                const double t3 = t2 * nt;
+                const double two_t3 = t3 * 2.0;
+                const double two_t2 = t2 * 2.0;
+                const double three_t2 = t2 * 3.0;
+                double4 hh;
+                hh.x = two_t3 - three_t2 + 1.0;
+                hh.y = t3 - two_t2 + nt;
+                hh.z = three_t2 - two_t3;
+                hh.w = t3 - t2;
+                hbt[r] = hh;
+            }
+            __syncthreads();
+            for (uint32_t i = i0 + tid; i < i1; i += CT) {
+                double sv;
+                if (i == n - 1) {
+                    sv = vals[K - 1];
+                } else {
+                    uint32_t sg = __umulhi(i, magic);
+                    if (sg > K - 2) sg = K - 2;
+                    const uint32_t t0i = sg * step;
+                    const bool last = (sg == K - 2);
+                    const double v0 = vals[sg], v1 = vals[sg + 1];
+                    if (sg > 0 && !last) {
+                        const double2 t = mms[sg - sgA];
+                        const double4 hh = hbt[i - t0i];
+                        sv = v0 * hh.x + t.x * hh.y + v1 * hh.z + t.y * hh.w;
+                    } else {
+                        const double nt = div_small((double)(i - t0i), last ? gapLd : stepd, last ? ryL : ry);
+                        sv = v0 * (1.0 - nt) + v1 * nt;
+                    }
+                }
+                double o = div1e5(round(sv * 100000.0));
+                if (o < mn) o = mn;
+                else if (o > mx) o = mx;
+                out[i] = o;
+            }
+            return;
+        }
+    }
     if (fs->status != 1) return;
     const uint32_t n = P.n, L = P.L, pre = P.pre;
     const float2 *tw = twpool + P.tw_off;
-    const double *xs = samples + fr.sample_off;
+    const double *xs = frame_samples(samples, fr);
     // LDS: [T 243 x 17 points][w1 243][wd 288][beg 256][end 256][list]
     float2 *T = (float2 *)smem;
     float2 *w1 = T + 243 * CSI;
@@ -635,6 +734,42 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     }
     __syncthreads();
     TSTAMP(3);
+    if constexpr (DECODE) {
+        // fft.rs:455-461: skip the padding, / L in f32, 5 decimals, clamp to the stored f32 range
+        if (live) {
+            double *out = frame_out(outp, fr);
+            const double mxd = (double)fs->mxf, mnd = (double)fs->mnf;
+            const float Lf = (float)L;
+            const bool pair_ok = (((uintptr_t)out & 15u) == 0);
+            auto val = [&](float re) -> double {
+                const float v = re / Lf;
+                double o = round((double)v * 100000.0) / 100000.0;
+                if (o > mxd) o = mxd;
+                if (o < mnd) o = mnd;
+                return o;
+            };
+#pragma unroll 1
+            for (uint32_t m = 0; m < 3; ++m) {
+                const uint32_t ka = q + 9u * m;
+                float2 b[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) b[j] = T[(j * 27 + ka) * CSI + c];
+                dft9f(b);
+#pragma unroll
+                for (int kq = 0; kq < 9; ++kq) {  // idft_L = 2 idft_M: even sample -> re, odd sample -> -im
+                    const uint32_t ja = ka + 27u * kq;
+                    const int32_t j2 = (int32_t)(2 * (FAST_MD * ja + jb)) - (int32_t)pre;  // even (pre and n are)
+                    if (j2 >= 0 && j2 < (int32_t)n) {
+                        const double o0 = val(2.0f * b[kq].x), o1 = val(-2.0f * b[kq].y);
+                        if (pair_ok) *(double2 *)(out + j2) = make_double2(o0, o1);
+                        else { out[j2] = o0; out[j2 + 1] = o1; }
+                    }
+                }
+            }
+        }
+        TSTAMP(4);
+        return;
+    }
     // Evaluation: ja = (q + 9 m) + 27 kq, samples 2 j and 2 j + 1, j = 288 ja + jb, against the padded signal (pre and n
     // are even for this class: a pair never straddles a frame edge).  The samples of group m + 1 are requested while
     // group m is transformed and evaluated.
@@ -772,6 +907,269 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
         }
     }
     if (tid == 0) fs->status = 2;
+}
+
+// Decoder: an FFT frame of 131072 samples (fft.rs:426-462) up to the point where k_large_trip243<true> takes over: the
+// payload's entries (rds_fft_entries: positions mirrored into [0, L/2], purely real bins' imaginary parts cleared), "later
+// entries overwrite earlier ones" (fft.rs:401-422: an entry is void when a later one names its position), the bucketed
+// list.  Anything else -- another codec, more entries than the encoder's first trip stores, a malformed payload (the
+// general decoder reports it) -- is left to k_decompress_large<0> (FastState::status stays 0).
+constexpr uint32_t FAST_DP_LDS = 512 + STG_BYTES + 4096 + 8 * FAST_K_MAX + 2 * 12 * (2 * FAST_K_MAX);
+__global__ __launch_bounds__(LT) void k_large_dparse(
+    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, const uint8_t *__restrict__ body, unsigned char *__restrict__ ws_base,
+    uint64_t ws_stride, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    unsigned long long dst_[6] = {0, 0, 0, 0, 0, 0};
+#define DSTAMP(i) do { if (dbg) dst_[i] = wall_clock64(); } while (0)
+    DSTAMP(0);
+    const DevDFrame fr = frames[ids[blockIdx.x]];
+    const DevPlan &P = plans[fr.plan];
+    const uint32_t L = P.L, M = P.M;
+    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    const LargeWs lay = large_ws_layout(fr.n, L, P.kcap);
+    FastState *fs = (FastState *)(ws + lay.o_front);
+    if (tid == 0) fs->status = 0;
+    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL) || P.f4_m1 != FAST_MF || P.f4_m2 != FAST_MD || !P.half ||
+        (P.pre & 1u) || (fr.n & 1u))
+        return;
+    // LDS: [hdr 512][payload window STG_BYTES][tab 1024 u32][pos FAST_K_MAX u32 + dead FAST_K_MAX u32][zl][zs]
+    uint32_t *bc = (uint32_t *)smem;
+    float *bcf = (float *)(smem + 64);
+    uint32_t *tab = (uint32_t *)(smem + 512 + STG_BYTES);
+    uint32_t *lpos = tab + 1024;
+    uint32_t *ldead = lpos + FAST_K_MAX;
+    SpEnt *zl = (SpEnt *)(ldead + FAST_K_MAX);
+    SpEnt *zs = zl + 2 * FAST_K_MAX;
+    Sel *ent = (Sel *)(ws + lay.o_sel);
+    const float2 *tw = twpool + P.tw_off;
+    // The whole payload into LDS first, by every thread (aligned dwords; the bytes in front of the payload belong to the
+    // record's header, the last partial dword is read byte by byte): the lock-step parser below then never refills its
+    // window -- a refill is 64 lanes copying 16 KB four bytes at a time, ~100 us for a payload of this size.
+    if (fr.payload_len + 4 > STG_BYTES) return;
+    const uint8_t *pay = body + fr.payload_off;
+    const uint32_t mis = (uint32_t)((uintptr_t)pay & 3u);
+    {
+        const uint32_t *src = (const uint32_t *)(pay - mis);
+        const uint32_t nd = (mis + fr.payload_len) >> 2;  // whole dwords
+        uint32_t *dst = (uint32_t *)(smem + 512);
+        for (uint32_t w = tid; w < nd; w += LT) dst[w] = src[w];
+        for (uint32_t b = 4 * nd + tid; b < mis + fr.payload_len; b += LT) (smem + 512)[b] = (pay - mis)[b];
+    }
+    __syncthreads();
+    DSTAMP(1);
+    // Header: id byte, varint count.  Then the entries -- 9 bytes (position < 251) or 11 (marker 251 + u16) each, so an
+    // entry's start depends on every entry before it.  One wavefront walking them in lock step (rds_fft_entries)
+    // took 88 us for 1310 entries; here next(o) = o + 9 or 11 is tabulated for EVERY byte offset o, squared six times
+    // (next^64), a single thread hops from group to group of 64 entries, and the sixteen wavefronts parse the
+    // groups side by side.
+    uint8_t *win = smem + 512 + mis;
+    if (fr.tag == ATSC_POLYNOMIAL) {
+        // Catmull-Rom frame (polynomial.rs:395-404): the points into the workspace as doubles, the rest is
+        // k_large_trip243<true>'s (one piece of the frame per workgroup).  Fixed-width points (F64 / U8) are read by
+        // every thread; varint points (I16 / I32) are found like the FFT entries below: next(o) = o + width tabulated
+        // for every byte offset, squared six times, groups of 64 values parsed side by side.
+        double *vals = (double *)(ws + lay.o_tab);
+        double *bcd = (double *)(smem + 128);
+        if (tid < 64) {
+            RdS r{pay, fr.payload_len, 0, false, win, 0, fr.payload_len, STG_BYTES};
+            const uint32_t id = (uint32_t)rds_varint(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t c64 = rds_varint(r);
+            if (tid == 0) {
+                bc[0] = (!r.bad && id == 0 && bd <= 3 && c64 >= 2 && c64 <= FAST_K_MAX && r.pos + 17 <= r.len) ? 1u : 0u;
+                bc[1] = (uint32_t)c64; bc[2] = r.pos; bc[3] = 0; bc[5] = bd;
+            }
+        }
+        __syncthreads();
+        if (!bc[0]) return;
+        const uint32_t K = bc[1], hdr = bc[2], bd = bc[5];
+        const uint32_t E = fr.payload_len - hdr - 17;  // bytes of the points
+        if (bd == 0 || bd == 3) {
+            if (E != K * (bd == 0 ? 8u : 1u)) return;
+            for (uint32_t k = tid; k < K; k += LT) {
+                if (bd == 3) {
+                    vals[k] = (double)win[hdr + k];
+                } else {
+                    uint64_t v = 0;
+                    for (int b = 0; b < 8; ++b) v |= (uint64_t)win[hdr + 8 * k + b] << (8 * b);
+                    vals[k] = __longlong_as_double((long long)v);
+                }
+            }
+        } else {
+            if (E < K || E > 9 * K) return;
+            uint16_t *Ja = (uint16_t *)zl, *Jb = Ja + STG_BYTES;
+            for (uint32_t o = tid; o <= E; o += LT) {
+                uint32_t nx = E;
+                if (o < E) {
+                    const uint32_t m = win[hdr + o];
+                    nx = o + (m < 251 ? 1u : m == 251 ? 3u : m == 252 ? 5u : 9u);
+                }
+                Ja[o] = (uint16_t)min(nx, E);
+            }
+            __syncthreads();
+            for (int k = 0; k < 6; ++k) {
+                for (uint32_t o = tid; o <= E; o += LT) Jb[o] = Ja[Ja[o]];
+                __syncthreads();
+                uint16_t *t = Ja; Ja = Jb; Jb = t;
+            }
+            uint32_t *cs = tab;
+            const uint32_t ngrp = (K + 63) / 64;
+            if (tid == 0) {
+                uint32_t o = 0;
+                for (uint32_t k = 0; k < ngrp; ++k) { cs[k] = o; o = Ja[o]; }
+                cs[ngrp] = E;
+            }
+            __syncthreads();
+            for (uint32_t k = tid >> 6; k < ngrp; k += LW) {
+                RdS r{pay, hdr + E, hdr + cs[k], false, win, 0, hdr + E, STG_BYTES};
+                const uint32_t grp = min(64u, K - 64 * k);
+                rds_varints(r, grp, [&](uint32_t i, uint64_t v) {
+                    vals[64 * k + i] = (bd == 2) ? (double)(int16_t)unzig(v) : (double)(int32_t)unzig(v);
+                });
+                if ((r.bad || r.pos != hdr + cs[k + 1]) && (tid & 63) == 0) atomicOr(&bc[3], 1u);
+            }
+            __syncthreads();
+            if (bc[3]) return;
+        }
+        if (tid == 0) {
+            uint64_t a = 0, b2 = 0;
+            for (uint32_t q = 0; q < 8; ++q) {
+                a |= (uint64_t)win[hdr + E + q] << (8 * q);
+                b2 |= (uint64_t)win[hdr + E + 8 + q] << (8 * q);
+            }
+            bcd[0] = __longlong_as_double((long long)a);
+            bcd[1] = __longlong_as_double((long long)b2);
+            bc[6] = win[hdr + E + 16];
+        }
+        __syncthreads();
+        const double mn = bcd[0], mx = bcd[1];
+        const uint32_t step = bc[6];
+        if (mx == mn || step < 16) return;  // a fill, or a step the piece kernel has no tables for: the general decoder
+        {
+            const uint32_t cntk = (fr.n + step - 1) / step;
+            const uint32_t Kp = cntk + (((cntk - 1) * step != fr.n - 1) ? 1u : 0u);
+            if (Kp != K) return;  // (the general decoder reports it)
+        }
+        if (tid == 0) {
+            fs->smin = mn; fs->smax = mx; fs->poly_K = K; fs->poly_step = step;
+            fs->status = 3;
+        }
+        return;
+    }
+    if (tid < 64) {
+        RdS r{pay, fr.payload_len, 0, false, win, 0, fr.payload_len, STG_BYTES};
+        (void)rds_u8(r);
+        const uint64_t cnt64 = rds_varint(r);
+        if (tid == 0) {
+            bc[0] = (!r.bad && cnt64 >= 1 && cnt64 <= FAST_K_MAX && r.pos + 8 <= r.len) ? 1u : 0u;
+            bc[1] = (uint32_t)cnt64;
+            bc[2] = r.pos;
+            bc[3] = 0;  // raised by a group that does not parse
+        }
+    }
+    __syncthreads();
+    if (!bc[0]) return;
+    const uint32_t cnt = bc[1], hdr = bc[2];
+    const uint32_t E = fr.payload_len - hdr - 8;  // bytes of the entries
+    if (E < 9 * cnt || E > 11 * cnt || ((11 * cnt - E) & 1u)) return;  // (left to the general decoder, which reports it)
+    {
+        uint16_t *Ja = (uint16_t *)zl, *Jb = Ja + STG_BYTES;  // two tables of E + 1 offsets (the list buffers are idle)
+        for (uint32_t o = tid; o <= E; o += LT) {
+            const uint32_t nx = o < E ? o + (win[hdr + o] < 251 ? 9u : 11u) : E;
+            Ja[o] = (uint16_t)min(nx, E);
+        }
+        __syncthreads();
+        for (int k = 0; k < 6; ++k) {
+            for (uint32_t o = tid; o <= E; o += LT) Jb[o] = Ja[Ja[o]];
+            __syncthreads();
+            uint16_t *t = Ja; Ja = Jb; Jb = t;
+        }
+        uint32_t *cs = tab;  // group starts (tab is free until the bucketing)
+        const uint32_t ngrp = (cnt + 63) / 64;
+        if (tid == 0) {
+            uint32_t o = 0;
+            for (uint32_t k = 0; k < ngrp; ++k) { cs[k] = o; o = Ja[o]; }
+            cs[ngrp] = E;
+        }
+        __syncthreads();
+        for (uint32_t k = tid >> 6; k < ngrp; k += LW) {
+            RdS r{pay, hdr + E, hdr + cs[k], false, win, 0, hdr + E, STG_BYTES};
+            const uint32_t grp = min(64u, cnt - 64 * k);
+            rds_fft_entries(r, grp, L, ent + 64 * k);
+            if ((r.bad || r.pos != hdr + cs[k + 1]) && (tid & 63) == 0) atomicOr(&bc[3], 1u);
+        }
+        __syncthreads();
+        if (bc[3]) return;
+        if (tid == 0) {
+            uint32_t a = 0, b2 = 0;
+            for (uint32_t q = 0; q < 4; ++q) {
+                a |= (uint32_t)win[hdr + E + q] << (8 * q);
+                b2 |= (uint32_t)win[hdr + E + 4 + q] << (8 * q);
+            }
+            bcf[0] = __uint_as_float(a);
+            bcf[1] = __uint_as_float(b2);
+        }
+        __syncthreads();
+    }
+    const float mxf = bcf[0], mnf = bcf[1];
+    if (mxf == mnf) return;  // a fill: left to the general decoder
+    DSTAMP(2);
+    // later entries overwrite earlier ones: entry i is void when a later one names its position.  A conforming stream
+    // names a position twice only through the `pos as u16` wrap, so a bitmap of the positions (8 KB of the idle list
+    // buffers) first tells whether any position repeats at all; only then every entry looks at the entries behind it.
+    uint32_t *bitmap = (uint32_t *)zs;  // 65536 bits
+    for (uint32_t i = tid; i < 2048; i += LT) bitmap[i] = 0;
+    for (uint32_t i = tid; i < FAST_K_MAX; i += LT) {
+        lpos[i] = i < cnt ? ent[i].pos : 0xFFFFFFFFu - i;
+        ldead[i] = 0;
+    }
+    if (tid == 0) bc[4] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += LT) {
+        const uint32_t p = lpos[i] & 0xffffu, bit = 1u << (p & 31u);
+        if (atomicOr(&bitmap[p >> 5], bit) & bit) bc[4] = 1;  // (positions are < 65536 after the mirroring: L / 2 = 69984)
+    }
+    __syncthreads();
+    if (bc[4]) {
+        for (uint32_t i = tid; i < cnt; i += LT) {
+            const uint32_t mine = lpos[i];
+            uint32_t dead = 0;
+            for (uint32_t j = (i + 1) & ~3u; j < ((cnt + 3u) & ~3u); j += 4) {  // (padding slots hold positions nobody has)
+                const uint4 p4 = *(const uint4 *)(lpos + j);
+                dead |= (j > i && p4.x == mine) | (j + 1 > i && p4.y == mine) | (j + 2 > i && p4.z == mine) |
+                        (j + 3 > i && p4.w == mine);
+            }
+            ldead[i] = dead;
+        }
+    }
+    __syncthreads();
+    DSTAMP(3);
+    const uint32_t nlist = fast_bucket(
+        cnt,
+        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
+            if (ldead[i]) return false;
+            const Sel e = ent[i];
+            p = e.pos;
+            if (p >= M) return false;  // (cannot be: positions are u16, M = 69984)
+            x = make_float2(e.re, e.im);
+            return true;
+        },
+        tw, M, zl, zs, tab, bc + 8, ws + lay.o_b);
+    if (tid == 0) {
+        fs->nlist = nlist;
+        fs->mxf = mxf;
+        fs->mnf = mnf;
+        fs->K1 = cnt;
+        fs->status = 1;
+    }
+    DSTAMP(4);
+    if (dbg && tid == 0 && blockIdx.x == 0)
+        printf("DSTAMP dparse: staging %.1f  parse %.1f  void entries %.1f  bucketing %.1f us (%u entries)\n",
+               (double)(dst_[1] - dst_[0]) * 0.01, (double)(dst_[2] - dst_[1]) * 0.01, (double)(dst_[3] - dst_[2]) * 0.01,
+               (double)(dst_[4] - dst_[3]) * 0.01, cnt);
 }
 
 constexpr uint32_t FAST_D1_LDS = 512 + 16384 + 8 * (FAST_OWN + 2 * FAST_K_MAX + FAST_CAND_MAX);
