@@ -16,8 +16,7 @@ hipError_t launch_compress_class(int, uint32_t, uint32_t, const double *, const 
 }
 hipError_t launch_compress_large(uint32_t, const double *, const DevFrame *, const uint32_t *, const DevPlan *,
                                  const float2 *, const KParams &, uint8_t *, DevResult *, atsc_frame_diag *,
-                                 unsigned char *, uint64_t, uint32_t, hipStream_t, const LargePre *, hipStream_t, hipEvent_t,
-                                 int *)
+                                 unsigned char *, uint64_t, uint32_t, hipStream_t, const LargePre *)
 {
     return hipErrorNotSupported;
 }
