@@ -1454,6 +1454,8 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     lap("alloc");
     FCHK(hipMemsetAsync(d_off + n_frames + parts, 0, sizeof(uint64_t), ws));
     FCHK(hipMemsetAsync(d_off + n_frames + 2 * parts + 1, 0, sizeof(uint64_t), ws));
+    uint64_t piece = 2u << 20;  // samples per copy call
+    if (const char *e2 = getenv("ATSC_H2D_PIECE_MB")) piece = (uint64_t)std::max(1, atoi(e2)) << 17;
     for (uint64_t g = 0; g < parts; ++g) {
         const uint64_t s0 = frame_off[pt[g].f0] - frame_off[0], s1 = frame_off[pt[g].f1] - frame_off[0];
         // (pieces of at most 16 MB: one pageable copy of 40 MB and more has been seen to take 10-15 ms -- the
@@ -1462,8 +1464,8 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
         // rest on a blocking copy having landed when it returns.  From pageable memory the call still returns only
         // once the bytes are staged, i.e. part g + 1 is being copied while part g's kernels run; from memory the
         // caller registered (atsc_host_register) the copies are true DMA transfers and the host runs ahead.
-        for (uint64_t c0 = s0; c0 < s1; c0 += (2u << 20)) {
-            const uint64_t c1 = std::min<uint64_t>(s1, c0 + (2u << 20));
+        for (uint64_t c0 = s0; c0 < s1; c0 += piece) {
+            const uint64_t c1 = std::min<uint64_t>(s1, c0 + piece);
             FCHK(hipMemcpyAsync(d_x + c0, samples + frame_off[0] + c0, (c1 - c0) * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->copy_stream));
         }

@@ -154,9 +154,9 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
         return blen.value
 
     nbytes, dt = timed(cf)
-    out["compress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "bytes": nbytes}
+    out["compress_frames_f256_pageable"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "bytes": nbytes}
     rec = bytes(body[:nbytes])
-    recarr = np.frombuffer(rec, dtype=np.uint8)
+    recarr = np.frombuffer(rec, dtype=np.uint8).copy()
     dec = np.empty(n, dtype=np.float64)
     on = C.c_uint64()
 
@@ -168,7 +168,24 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
 
     got, dt = timed(df)
     assert got == n
-    out["decompress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
+    out["decompress_frames_f256_pageable"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
+    # the same two calls on buffers the caller page-locked once (atsc_host_register: what a long-lived host process
+    # does with its ingest and result buffers): the copies become DMA transfers the host does not wait behind
+    regs = [(x, x.nbytes), (body, body.nbytes), (recarr, recarr.nbytes), (dec, dec.nbytes)]
+    done = []
+    try:
+        for a, nb in regs:
+            atsc_amd.capi.check(lib.atsc_host_register(C.c_void_p(a.ctypes.data), nb), ctx._h)
+            done.append(a)
+        nb2, dt = timed(cf)
+        assert nb2 == nbytes and bytes(body[:nbytes]) == rec
+        out["compress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "bytes": nbytes}
+        got, dt = timed(df)
+        assert got == n
+        out["decompress_frames_f256"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
+    finally:
+        for a in done:
+            lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
     # atsc_compress_data / atsc_decompress_data: the atsc CLI's calls, reference chunker framing (80 x 131072)
     bro = C.POINTER(C.c_uint8)()
     ln = C.c_uint64()
@@ -197,7 +214,8 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
     got, dt = timed(dd)
     assert got == n
     out["decompress_data_chunker"] = {"value": n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3}
-    out["note"] = "host buffer -> host buffer, PCIe inclusive, median of %d calls; pageable caller memory" % reps
+    out["note"] = ("host buffer -> host buffer, PCIe inclusive, median of %d calls; *_f256: caller buffers registered "
+                   "once with atsc_host_register; *_pageable and *_chunker: pageable caller memory" % reps)
     return out
 
 
