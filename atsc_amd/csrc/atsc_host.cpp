@@ -950,7 +950,8 @@ static int ensure_chain(atsc_ctx *ctx, const atsc_plan *plan, uint32_t c, bool f
 {
     atsc_plan::Chain &ch = plan->chains[q];  // set q (scratch, events), run on chain stream c
     if (!ctx->chain_streams[c]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->chain_streams[c], hipStreamNonBlocking));
-    if (full && !ctx->pack_streams[c]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_streams[c], hipStreamNonBlocking));
+    // (the pack stream is made when a call first packs on it: a process has a handful of hardware queues, the
+    // runtime deals streams over them, and a stream nobody uses still takes its turn in that deal)
     if (!ch.ev_fork) {
         HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_fork, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_lfork, hipEventDisableTiming));
@@ -1060,7 +1061,14 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     const bool adapt = pipelined && ctx->adaptive_order;
     bool want_order = false;  // set once the main launches (which record the costs) are enqueued
     const uint32_t *ids_main = (adapt && CH.adapt_valid) ? CH.d_ids_adapt : plan->d_ids;
-    static const bool pack_apart = getenv("ATSC_PACK_SAME_STREAM") == nullptr;
+    // Where the records are packed.  One chain: on a stream of its own, beside the chain's next codecs.  Two chains
+    // and more: on the chain's stream, behind its codecs -- the other chains' codecs run beside it, and every stream
+    // saved matters: the runtime maps streams onto a few hardware queues (four by default), and a chain that shares
+    // its queue with another chain's packing waits behind that packing's wait for *its* codecs.  Measured on the
+    // 10.5 M-sample batch, two chains: 115.5 us per step with packing streams, 106.4 without (104.8 with
+    // GPU_MAX_HW_QUEUES=8 and packing streams, i.e. no sharing); tools/chain_stamp_probe.py shows the stalls.
+    static const bool pack_same_env = getenv("ATSC_PACK_SAME_STREAM") != nullptr, pack_apart_env = getenv("ATSC_PACK_APART") != nullptr;
+    const bool pack_apart = pipelined && !pack_same_env && (pack_apart_env || plan_chains(ctx, plan) == 1);
     bool codec_attached = false;  // ev_codec is the stop event of this call's last codec dispatch
     auto pack = [&]() -> int {
         for (uint32_t g = 0; g < large_groups; ++g)
@@ -1069,6 +1077,7 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         if (pipelined) {
             if (!codec_attached) HIPCHK(ctx, hipEventRecord(CH.ev_codec, s));  // nothing reads d_samples from here on
             if (pack_apart) {  // the packing runs beside the chain's next codecs
+                if (!ctx->pack_streams[ci]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pack_streams[ci], hipStreamNonBlocking));
                 ps = ctx->pack_streams[ci];
                 HIPCHK(ctx, hipStreamWaitEvent(ps, CH.ev_codec, 0));
             }
@@ -1114,6 +1123,9 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     prm.bounded = bounded;
     prm.want_diag = ctx->want_diag;
     prm.debug_stop = ctx->debug_stop;
+#ifdef ATSC_STAMPS
+    prm.debug_stop = (int32_t)((qi & 3u) << 24);  // dev build: the frame-span stamps are kept per scratch set
+#endif
     atsc_frame_diag *d_diag = nullptr;
     if (ctx->want_diag) {
         if (ctx->diag_cap < plan->n_frames) {
@@ -1433,6 +1445,8 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     }
     lap("plans");
     int rc = ATSC_OK;
+    uint64_t piece = 2u << 20;  // samples per copy call
+    if (const char *e2 = getenv("ATSC_H2D_PIECE_MB")) piece = (uint64_t)std::max(1, atoi(e2)) << 17;
     double *d_x = nullptr, *d_err = nullptr;
     uint8_t *d_body = nullptr, *d_ch = nullptr;
     uint64_t *d_off = nullptr;  // part g's n_g + 1 offsets start at f0_g + g; then parts + 1 chain words:
@@ -1454,8 +1468,6 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     lap("alloc");
     FCHK(hipMemsetAsync(d_off + n_frames + parts, 0, sizeof(uint64_t), ws));
     FCHK(hipMemsetAsync(d_off + n_frames + 2 * parts + 1, 0, sizeof(uint64_t), ws));
-    uint64_t piece = 2u << 20;  // samples per copy call
-    if (const char *e2 = getenv("ATSC_H2D_PIECE_MB")) piece = (uint64_t)std::max(1, atoi(e2)) << 17;
     for (uint64_t g = 0; g < parts; ++g) {
         const uint64_t s0 = frame_off[pt[g].f0] - frame_off[0], s1 = frame_off[pt[g].f1] - frame_off[0];
         // (pieces of at most 16 MB: one pageable copy of 40 MB and more has been seen to take 10-15 ms -- the

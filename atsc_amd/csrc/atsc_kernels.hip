@@ -259,7 +259,7 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
 // one-wavefront kernel.  A frame sums its phases in LDS (128 static bytes: 22 instead of 23 frames per CU) and
 // adds them to one of 64 global rows when it ends.
 __device__ unsigned long long g_phase_cyc[64 * 16];
-__device__ unsigned long long g_frame_span[65536 * 3];  // wall clock (100 MHz) at a frame's start and end, by launch slot; HW_ID | XCC_ID << 32
+__device__ unsigned long long g_frame_span[4 * 65536 * 3];  // wall clock (100 MHz) at a frame's start and end, by launch slot; HW_ID | XCC_ID << 32
 #define PH(i) do { if (FN != 0) { const long long now_ = clock64(); \
     if (tid == 0) atomicAdd(&ph_acc[i], (unsigned long long)(now_ - ph_t)); ph_t = clock64(); } } while (0)
 #else
@@ -286,9 +286,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     if (tid < 16) ph_acc[tid] = 0;
     __syncthreads();
     long long ph_t = clock64();
+    const uint32_t span0 = 3u * 65536u * (((uint32_t)prm.debug_stop >> 24) & 3u);
     if (FN != 0 && tid == 0 && blockIdx.x < 65536) {
-        g_frame_span[3 * blockIdx.x] = wall_clock64();
-        g_frame_span[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+        g_frame_span[span0 + 3 * blockIdx.x] = wall_clock64();
+        g_frame_span[span0 + 3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
                                            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
     }
 #endif
@@ -1508,7 +1509,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
 #ifdef ATSC_STAMPS
     __syncthreads();
     if (FN != 0 && tid < 16) atomicAdd(&g_phase_cyc[(fid & 63u) * 16 + tid], ph_acc[tid]);
-    if (FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[3 * blockIdx.x + 1] = wall_clock64();
+    if (FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[span0 + 3 * blockIdx.x + 1] = wall_clock64();
 #endif
     if (tid == 0) {
         res[fid].err = chosen_err;
@@ -1908,7 +1909,7 @@ static hipError_t launch_class(uint32_t count, uint32_t lds, const double *sampl
         return launch_class2<W, SPL, true, 0>(count, lds, samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, s, ev0, ev1);
     // uniform launches of the power-of-two frame lengths the reference chunker emits (256 is also
     // BASELINE's framing) take the instantiation with the frame geometry folded in
-    const bool lean_ok = diag == nullptr && prm.debug_stop == 0 && !prm.trial && prm.trial_res == nullptr &&
+    const bool lean_ok = diag == nullptr && (prm.debug_stop & 0xffffff) == 0 && !prm.trial && prm.trial_res == nullptr &&
                          prm.mode == ATSC_AUTO && prm.bounded && 0.0 <= prm.max_err;
     if (uni.enabled && lean_ok) {
         if constexpr (W == 1 && SPL == 5) {
@@ -2039,5 +2040,11 @@ extern "C" __attribute__((visibility("default"))) int atsc_dev_phase_read(unsign
 extern "C" __attribute__((visibility("default"))) int atsc_dev_span_read(unsigned long long *out, unsigned n_frames)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(atsc::g_frame_span), sizeof(unsigned long long) * 3 * n_frames) == hipSuccess ? 0 : -1;
+}
+// the stamps of scratch set `set` (pipelined calls: set = turn % (2 * chains))
+extern "C" __attribute__((visibility("default"))) int atsc_dev_span_read_set(unsigned long long *out, unsigned n_frames, unsigned set)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(atsc::g_frame_span), sizeof(unsigned long long) * 3 * n_frames,
+                               sizeof(unsigned long long) * 3 * 65536 * (set & 3u)) == hipSuccess ? 0 : -1;
 }
 #endif
