@@ -43,8 +43,14 @@ HEADERS = ["atsc_device.h", "atsc_internal.h", "atsc_large_cols.h", "atsc_large_
 CFLAGS = [f for f in FLAGS if f != "-shared"] + os.environ.get("ATSC_BUILD_DEFS", "").split()
 
 
-def _flags_key():
-    return " ".join(CFLAGS)
+# per-source additions to CFLAGS
+FILE_FLAGS = {}
+if os.environ.get("ATSC_BUILD_NO_MLICM"):
+    FILE_FLAGS["atsc_kernels.hip"] = ["-mllvm", "-disable-machine-licm"]
+
+
+def _flags_key(src=None):
+    return " ".join(CFLAGS + FILE_FLAGS.get(src, []))
 
 
 def _obj_stale(src, obj):
@@ -53,7 +59,7 @@ def _obj_stale(src, obj):
     if not os.path.exists(obj):
         return True
     try:
-        if open(obj + ".flags").read() != _flags_key():
+        if open(obj + ".flags").read() != _flags_key(src):
             return True
     except OSError:
         return True
@@ -70,7 +76,7 @@ def _compile_objects(force, verbose):
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _obj_stale(s, obj):
-            cmd = [_hipcc()] + CFLAGS + ["-c", "-o", obj, os.path.join(CSRC, s)]
+            cmd = [_hipcc()] + CFLAGS + FILE_FLAGS.get(s, []) + ["-c", "-o", obj, os.path.join(CSRC, s)]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((s, obj, subprocess.Popen(cmd, cwd=CSRC)))
@@ -80,7 +86,7 @@ def _compile_objects(force, verbose):
             bad.append(s)
         else:
             with open(obj + ".flags", "w") as f:
-                f.write(_flags_key())
+                f.write(_flags_key(s))
     if bad:
         raise RuntimeError("hipcc failed on " + ", ".join(bad))
     return objs

@@ -13,6 +13,17 @@
 namespace atsc {
 
 #define DEVI __device__ __forceinline__
+// threadIdx.x through an opaque move: code built on it cannot be hoisted out of a loop over frames (k_compress_resident),
+// where every per-lane address and constant would otherwise stay in registers across the whole frame body
+template <int W = 0>
+DEVI uint32_t tid_now()
+{
+    // one-wavefront workgroups: the lane count below this lane (two instructions) instead of the thread-id register,
+    // which the resident kernel's register allocation would rather spill than keep for the whole loop
+    uint32_t t = (W == 1) ? __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) and size step instead of once per
 // launch: in a process that has many code objects loaded (PyTorch) one such call was measured at ~5 ms, and
@@ -255,7 +266,7 @@ DEVI double block_sum_f64(double v, double *red, int &parity)
     if (W == 1) return v;
     double *r = red + parity * 16;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    if ((tid_now<W>() & 63) == 0) r[tid_now<W>() >> 6] = v;
     __syncthreads();
     double s = r[0];
 #pragma unroll
@@ -269,7 +280,7 @@ DEVI uint32_t block_sum_u32(uint32_t v, double *red, int &parity)
     if (W == 1) return v;
     uint32_t *r = (uint32_t *)(red + parity * 16);
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    if ((tid_now<W>() & 63) == 0) r[tid_now<W>() >> 6] = v;
     __syncthreads();
     uint32_t s = r[0];
 #pragma unroll
@@ -314,7 +325,7 @@ DEVI double block_minmax_f64(double v, double *red, int &parity)
     if (W == 1) return v;
     double *r = red + parity * 16;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    if ((tid_now<W>() & 63) == 0) r[tid_now<W>() >> 6] = v;
     __syncthreads();
     double s = r[0];
 #pragma unroll
@@ -331,7 +342,7 @@ DEVI uint32_t block_min_u32(uint32_t v, double *red, int &parity)
     if (W == 1) return v;
     uint32_t *r = (uint32_t *)(red + parity * 16);
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    if ((tid_now<W>() & 63) == 0) r[tid_now<W>() >> 6] = v;
     __syncthreads();
     uint32_t s = r[0];
 #pragma unroll
@@ -375,7 +386,7 @@ template <int W>
 DEVI uint32_t block_excl_scan(uint32_t *arr, uint32_t count, uint32_t *wsum)
 {
     constexpr int T = 64 * W;
-    const int tid = threadIdx.x;
+    const int tid = tid_now<W>();
     if (W == 1 && count <= 64) {  // one entry per lane: the payload emitters and the few-runs RLE
         const uint32_t v = (uint32_t)tid < count ? arr[tid] : 0u;
         const uint32_t in = wave_incl_scan_u32(v);
@@ -415,7 +426,7 @@ template <int W, bool KeyOnly>
 DEVI void block_sort(uint64_t *keys, uint32_t *pay, uint32_t count, uint32_t P2)
 {
     constexpr int T = 64 * W;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = tid_now<W>();
     const uint32_t npairs = P2 >> 1;
     auto ce = [&](uint32_t i, uint32_t l) {
         if (l < count) {

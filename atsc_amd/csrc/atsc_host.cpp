@@ -81,6 +81,11 @@ struct atsc_ctx {
     //    (tools/gap_probe.hip), and a frame kernel's freed wave slots refill slowly from a single queue; several queues
     //    feeding the same CUs hide both (what bench.py --chains did from outside in round 2);
     //  * the large tier: see large groups below.
+    // resident launches (k_compress_resident): one set of frame counters per stream that has carried one (launches
+    // on a stream are sequential, and a launch leaves its counters zero)
+    uint32_t *d_queues = nullptr;
+    hipStream_t q_stream[16] = {};
+    uint32_t q_used = 0;
     hipStream_t chain_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t pack_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // a chain's packing: beside its next batch's codecs
     int n_chains = 2;                   // atsc_ctx_set_chains / ATSC_CHAINS (1..4)
@@ -563,6 +568,7 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     for (auto &cs : ctx->chain_streams)
         if (cs) (void)hipStreamDestroy(cs);
     for (auto &cs : ctx->pack_streams)
@@ -1272,6 +1278,24 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
             u.adaptive = (ids_main != plan->d_ids) ? 1u : 0u;
             u.count = plan->class_count[c];
             u.spread = 0;
+            static const bool resident_on = getenv("ATSC_RESIDENT") != nullptr;
+            if (resident_on && u.enabled && compressor == ATSC_AUTO && bounded && 0.0 <= prm.max_err && !d_diag &&
+                (prm.debug_stop & 0xffffff) == 0 && !prm.trial && !prm.trial_res) {
+                const uint32_t g = resident_grid(c, u.n, plan->class_lds[c]);
+                if (g && u.count >= 2 * g) {
+                    if (!ctx->d_queues) {
+                        HIPCHK(ctx, hipMalloc((void **)&ctx->d_queues, 16 * RESIDENT_Q_WORDS * sizeof(uint32_t)));
+                        HIPCHK(ctx, hipMemset(ctx->d_queues, 0, 16 * RESIDENT_Q_WORDS * sizeof(uint32_t)));
+                    }
+                    uint32_t qx = 0;
+                    while (qx < ctx->q_used && ctx->q_stream[qx] != s) ++qx;
+                    if (qx == ctx->q_used && qx < 16) { ctx->q_stream[qx] = s; ctx->q_used++; }
+                    if (qx < 16) {
+                        u.queue = ctx->d_queues + RESIDENT_Q_WORDS * qx;
+                        u.q_grid = g;
+                    }
+                }
+            }
             static const bool no_spread = getenv("ATSC_NO_SPREAD") != nullptr;
             if (u.enabled && !u.adaptive && !no_spread && u.count >= 4096) {
                 // a stride near count / golden ratio, made coprime to count

@@ -155,7 +155,15 @@ struct UniArgs {
     uint32_t n;
     uint32_t plan;
     uint32_t spread, count;  // spread != 0: workgroup b takes frame (b * spread) % count of the class (spread coprime to count)
+    // resident launch (k_compress_resident): q_grid workgroups take frames from the counters at queue
+    // (RESIDENT_Q_WORDS words, zero between launches; one set per stream)
+    uint32_t *queue;
+    uint32_t q_grid, q_pad;
 };
+constexpr uint32_t RESIDENT_Q_WORDS = 288;  // eight heads and the exit count, a 128-byte line each
+// workgroups a resident launch of class `cls` with frames of n samples and `lds` bytes of LDS takes (0: that class /
+// length has no resident instantiation)
+uint32_t resident_grid(int cls, uint32_t n, uint32_t lds);
 
 // parsed frame record for decompression
 struct DevDFrame {

@@ -53,7 +53,7 @@ DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *t
         const uint32_t nb = M / r;
         const uint32_t magic = P.stmagic[s];
         const uint32_t sm = st * m;
-        for (uint32_t t = threadIdx.x; t < nb; t += T) {
+        for (uint32_t t = tid_now<W>(); t < nb; t += T) {
             const uint32_t p = (st == 1) ? t : __umulhi(t, magic);  // t / st
             const uint32_t q = t - p * st;
             const uint32_t ib = q + st * p;        // + st*m*j
@@ -102,7 +102,7 @@ DEVI void fft_untangle(const DevPlan &P, const float2 *Z, float2 *out, const flo
 {
     constexpr int T = 64 * W;
     const uint32_t M = P.M;
-    for (uint32_t k = threadIdx.x; k <= M; k += T) {
+    for (uint32_t k = tid_now<W>(); k <= M; k += T) {
         const float2 zk = Z[k == M ? 0 : k];
         const float2 zm = Z[k == 0 ? 0 : M - k];
         const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);   // Z[k] + conj Z[M-k]
@@ -121,7 +121,7 @@ DEVI void fft_stage_fixed(const float2 *X, float2 *Y, const float2 *tw)
 {
     constexpr int T = 64 * W;
     constexpr uint32_t nb = M / R, m = (M / ST) / R, sm = ST * m;
-    for (uint32_t t = threadIdx.x; t < nb; t += T) {
+    for (uint32_t t = tid_now<W>(); t < nb; t += T) {
         const uint32_t p = t / ST, q = t - p * ST;
         const uint32_t ib = t, ob = q + ST * (R * p), tb = p * ST * SC;
         if (R == 4) {
@@ -172,7 +172,7 @@ DEVI void fft_untangle_fixed(const float2 *Z, float2 *out, const float2 *tw)
     constexpr int T = 64 * W;
 #pragma unroll
     for (uint32_t k0 = 0; k0 <= M; k0 += T) {
-        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t k = k0 + tid_now<W>();
         if (k <= M) {
             const float2 zk = Z[k == M ? 0 : k];
             const float2 zm = Z[k == 0 ? 0 : M - k];
@@ -201,7 +201,7 @@ DEVI void dft_direct(const DevPlan &P, const double *xs, float2 *out, const floa
 {
     constexpr int T = 64 * W;
     const uint32_t n = P.L;
-    for (uint32_t k = threadIdx.x; k < P.bins; k += T) {
+    for (uint32_t k = tid_now<W>(); k < P.bins; k += T) {
         double re = 0.0, im = 0.0;
         uint32_t idx = 0;
         for (uint32_t j = 0; j < n; ++j) {
@@ -223,7 +223,7 @@ template <int W>
 DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint32_t P2)
 {
     constexpr int T = 64 * W;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = tid_now<W>();
     const uint32_t npairs = P2 >> 1;
     auto ce = [&](uint32_t i, uint32_t l) {
         if (l < count) {
@@ -268,16 +268,30 @@ __device__ unsigned long long g_frame_span[4 * 65536 * 3];  // wall clock (100 M
 // one-wavefront frames of the 256-sample class: ask for 6 wavefronts per SIMD (<= 80 VGPRs).
 // FN != 0: every frame of the launch has FN samples (FN >= 128, even transform length) and the frame
 // geometry is folded at compile time; FN == 0 reads it from the per-length table.
+DEVI void frame_prio(uint32_t trips)  // (s_setprio takes an immediate)
+{
+    if (trips == 3) __builtin_amdgcn_s_setprio(1);
+    else if (trips == 7) __builtin_amdgcn_s_setprio(2);
+    else if (trips == 12) __builtin_amdgcn_s_setprio(3);
+}
+
 template <int W, int SPL, bool IDW, int FN, bool LEAN_ = (FN != 0)>
-__global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void k_compress(
+__device__ __forceinline__ void compress_frame(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
-    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
-    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, const UniArgs uni)
+    const float2 *__restrict__ twpool, const KParams &prm, uint8_t *__restrict__ slots,
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, const UniArgs &uni, const uint32_t bid)
 {
     constexpr int T = 64 * W;
+    constexpr bool FIX_ = FN != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = tid_now<W>();  // (opaque: see tid_now)
+    // Issue priority follows the frame's age in ladder trips (frame_prio below): a frame that is still going after
+    // several trips is one of the launch's long ones, and the sooner those end the shorter the launch's tail.  It
+    // matters most for resident workgroups (k_compress_resident): their wavefronts were all started together, so
+    // the hardware's oldest-first arbitration ranks them once and for all, and the last of a SIMD's five would take
+    // 100 us and more over a frame that takes 15.
+    if (W == 1) __builtin_amdgcn_s_setprio(0);
     uint32_t fid;
     DevFrame fr;
     const long long t_start = prm.cost ? clock64() : 0;
@@ -287,28 +301,35 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
     __syncthreads();
     long long ph_t = clock64();
     const uint32_t span0 = 3u * 65536u * (((uint32_t)prm.debug_stop >> 24) & 3u);
-    if (FN != 0 && tid == 0 && blockIdx.x < 65536) {
-        g_frame_span[span0 + 3 * blockIdx.x] = wall_clock64();
-        g_frame_span[span0 + 3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+    if (FN != 0 && tid == 0 && bid < 65536) {
+        g_frame_span[span0 + 3 * bid] = wall_clock64();
+        g_frame_span[span0 + 3 * bid + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
                                            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
     }
 #endif
-    if (uni.enabled) {
+    if (FIX_ || uni.enabled) {  // (the fixed-length kernels are only launched on uniform classes)
         // Index order starts the frames series block by series block: when the last block of a batch is a busy one the
         // launch drains on a few CUs.  Without a cost order the frames are dealt with a fixed stride instead, so that
         // every stretch of the launch is a mix of the batch's blocks (results are positional: nothing else changes).
-        const uint32_t r = uni.adaptive ? ids[blockIdx.x] - uni.fid0
-                           : uni.spread ? (uint32_t)(((uint64_t)blockIdx.x * uni.spread) % uni.count) : blockIdx.x;
+        // (the same for every lane; said so, because a pointer that reached this function through memory makes
+        // the load a per-lane one and everything derived from it per-lane arithmetic)
+        const uint32_t r = uni.adaptive ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(ids[bid] - uni.fid0))
+                           : uni.spread ? (uint32_t)(((uint64_t)bid * uni.spread) % uni.count) : bid;
         fid = uni.fid0 + r;
         fr.sample_off = uni.sample_off0 + (uint64_t)r * uni.n;
         fr.slot_off = uni.slot_off0 + (uint64_t)r * uni.slot_stride;
         fr.n = uni.n;
         fr.plan = uni.plan;
     } else {
-        fid = ids[blockIdx.x];
+        fid = ids[bid];
         fr = frames[fid];
     }
-    const DevPlan &P = plans[fr.plan];
+    // (through the constant address space: the plan table is read-only for the life of the kernel, and a pointer that
+    // reached this function through memory -- k_compress_resident -- carries no such promise by itself; without it
+    // every table read is a vector load that has to be repeated after each store)
+    typedef const __attribute__((address_space(4))) DevPlan PlanConst;
+    PlanConst &P = *(PlanConst *)(plans + fr.plan);
+#define P_GENERIC (*(const DevPlan *)&P)  // for the helpers that take the plan by (generic) reference
     constexpr bool FIX = FN != 0;
     // The fixed-length instantiations are the production path: no diagnostics record, no phase stops, no
     // sample-level trial (launch_class routes those calls to the table-driven instantiation).  Their
@@ -720,6 +741,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     const uint32_t K = P.pK[ti];
                     if (prune && !can_win(poly_payload_size(step, K), 1)) { poly_pruned = true; break; }
                     ++poly_trips;
+                    if (W == 1) frame_prio(poly_trips);
                     poly_step = step;
                     poly_K = K;
                     if (IDW && step > 1 && idw) {
@@ -928,7 +950,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 spec = fft_forward_fixed<W, FIX ? cM : 3, 1>(A, B, tw);
             } else if (P.direct) {
                 __syncthreads();
-                dft_direct<W>(P, xs, A, tw);
+                dft_direct<W>(P_GENERIC, xs, A, tw);
                 spec = A;
             } else if (P.half) {
                 float *Af = (float *)A;  // z[j] = g[2j] + i g[2j+1]  ==  g stored as consecutive f32
@@ -938,9 +960,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     if (j < L) Af[j] = (float)g[m];
                 }
                 __syncthreads();
-                float2 *Z = fft_forward<W>(P, A, B, tw);
+                float2 *Z = fft_forward<W>(P_GENERIC, A, B, tw);
                 spec = (Z == A) ? B : A;
-                fft_untangle<W>(P, Z, spec, tw);
+                fft_untangle<W>(P_GENERIC, Z, spec, tw);
             } else {
 #pragma unroll
                 for (int m = 0; m < SPL; ++m) {
@@ -948,7 +970,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                     if (j < L) A[j] = make_float2((float)g[m], 0.0f);
                 }
                 __syncthreads();
-                spec = fft_forward<W>(P, A, B, tw);
+                spec = fft_forward<W>(P_GENERIC, A, B, tw);
             }
             PH(5);
             if (!LEAN && prm.debug_stop == 4) return;
@@ -1090,6 +1112,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
                 const uint32_t K = min(mf + jump, Z);
                 if (prune && !can_win(1 + vlen(K) + 9 * K + 8, 0)) { fft_pruned = true; break; }
                 ++fft_trips;
+                if (W == 1) frame_prio(fft_trips);
                 if (W > 1 && !heap_order && K > sorted_n) {
                     const uint32_t first = mf + 2 * dk1;
                     build_order((K <= first && first < kcap) ? first : kcap);
@@ -1509,7 +1532,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
 #ifdef ATSC_STAMPS
     __syncthreads();
     if (FN != 0 && tid < 16) atomicAdd(&g_phase_cyc[(fid & 63u) * 16 + tid], ph_acc[tid]);
-    if (FN != 0 && tid == 0 && blockIdx.x < 65536) g_frame_span[span0 + 3 * blockIdx.x + 1] = wall_clock64();
+    if (FN != 0 && tid == 0 && bid < 65536) g_frame_span[span0 + 3 * bid + 1] = wall_clock64();
 #endif
     if (tid == 0) {
         res[fid].err = chosen_err;
@@ -1517,6 +1540,98 @@ __global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void 
         res[fid].chosen = (uint32_t)chosen;
         if (!LEAN && diag) diag[fid] = dg;
         if (prm.cost) prm.cost[fid] = (uint32_t)min((unsigned long long)(clock64() - t_start) >> 6, 0xFFFFFFFFull);
+    }
+}
+
+// One frame per workgroup: the grid is the class's frame list.
+template <int W, int SPL, bool IDW, int FN, bool LEAN_ = (FN != 0)>
+__global__ __launch_bounds__(64 * W, (W == 1 && SPL <= 5 && !IDW) ? 6 : 1) void k_compress(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+    const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, const UniArgs uni)
+{
+    compress_frame<W, SPL, IDW, FN, LEAN_>(samples, frames, ids, plans, twpool, prm, slots, res, diag, uni, blockIdx.x);
+}
+
+// Resident workgroups: as many as the GPU holds at once, each taking the next frame of the class from a counter
+// until the list is done.  A workgroup slot that has to be refilled by the dispatcher stays empty for 1-2.5 us
+// (tools/dispatch_probe.hip: 40960 workgroups of 10 us each with 7008 bytes of LDS keep 18.7 of a CU's 23 slots
+// busy); a 256-sample frame lives 13 us.  queue[0] counts the frames handed out since the counter was made; the
+// launch's share starts at q_base (the host adds every launch's count), so nothing resets it.
+struct ResidentArgs {
+    const double *samples;
+    const DevFrame *frames;
+    const uint32_t *ids;
+    const DevPlan *plans;
+    const float2 *twpool;
+    KParams prm;
+    uint8_t *slots;
+    DevResult *res;
+    atsc_frame_diag *diag;
+    UniArgs uni;
+    uint32_t *queue;  // RESIDENT_Q_WORDS words: head x at word 32 x (a 128-byte line each), x < 8; exits at word 256
+    uint32_t count;
+};
+// Resident workgroups: as many as the GPU holds at once (resident_grid), each taking frame after frame of the
+// class until none is left.  A workgroup slot the dispatcher has to refill stays empty for 1-2.5 us
+// (tools/dispatch_probe.hip: 40960 workgroups that live 10 us each with 7008 bytes of LDS keep 18.7 of a CU's 23
+// slots busy), a 256-sample frame lives 13 us, and a second launch's workgroups only get on the GPU as these leave:
+// its head fills this launch's tail.
+// The frame list is cut into eight contiguous shares with a head counter each, and a workgroup starts on the share
+// of the XCD it runs on: one counter word takes ~88 returning atomics per microsecond (MI355X_MICROARCH.md,
+// "dequeue") where this kernel asks for ~400; when its share is done it goes on to the next XCD's, so the shares'
+// different costs even out.  The last workgroup to leave zeroes the counters for the next launch on the stream.
+// STATUS: an experiment behind ATSC_RESIDENT=1, not the default.  Measured on the 10.5 M-sample batch (two chains):
+// 170 us per step against 106 for one workgroup per frame.  The slots do stay full (4830 frames in flight against
+// 4700) and the refill gap shrinks from 2.7 to 1.1 us, but the returning device-scope adds of ~5000 pullers cost
+// more than that: a launch ends in a 70-us tail in which the last few hundred frames live 80 us each, fewer
+// resident workgroups are FASTER (16 per CU: 158 us, 22: 176), and a relaxed agent-scope load of the head in front
+// of every add (to spare the failing adds) took the whole launch to 480 us with every frame's life doubled --
+// the queue traffic slows the frames' own memory operations.  DESIGN.md section 3 has the numbers.
+template <int W, int SPL, bool IDW, int FN, bool LEAN_ = (FN != 0)>
+__global__ __launch_bounds__(64 * W, 5) void k_compress_resident(const ResidentArgs args)
+{
+    // The arguments are read where they are used, through the kernel-argument segment's own pointer made opaque once
+    // per frame: held in registers across the loop they would take ~60 scalar registers from the frame's code.
+    typedef const __attribute__((address_space(4))) ResidentArgs *ArgPtr;
+    ArgPtr ka = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ uint32_t q_bid, q_cur, q_tried;
+    if (threadIdx.x == 0) {
+        q_cur = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;  // XCC_ID
+        q_tried = 0;
+    }
+    for (;;) {
+        asm volatile("" : "+s"(ka));
+        if (threadIdx.x == 0) {
+            const uint32_t count = ka->count, per = (count + 7u) >> 3;
+            uint32_t *q = ka->queue;
+            uint32_t cur = q_cur, tried = q_tried, b = 0xFFFFFFFFu;
+            while (tried < 8) {
+                const uint32_t start = cur * per;
+                const uint32_t size = start < count ? min(per, count - start) : 0u;
+                const uint32_t i = size ? atomicAdd(&q[32 * cur], 1u) : 0xFFFFFFFFu;
+                if (i < size) { b = start + i; break; }
+                cur = (cur + 1) & 7u;
+                ++tried;
+            }
+            q_cur = cur;
+            q_tried = tried;
+            q_bid = b;
+        }
+        __syncthreads();
+        const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_bid);
+        __syncthreads();
+        if (bid == 0xFFFFFFFFu) break;
+        compress_frame<W, SPL, IDW, FN, LEAN_>(ka->samples, ka->frames, ka->ids, ka->plans, ka->twpool, *(const KParams *)&ka->prm,
+                                               ka->slots, ka->res, ka->diag, *(const UniArgs *)&ka->uni, bid);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t *q = ka->queue;
+        if (atomicAdd(&q[256], 1u) == gridDim.x - 1) {  // everybody else has made its last request
+            for (int x = 0; x < 8; ++x) q[32 * x] = 0;
+            q[256] = 0;
+        }
     }
 }
 
@@ -1893,9 +2008,37 @@ static hipError_t launch_class2(uint32_t count, uint32_t lds, const double *samp
     }
     // ev0 / ev1 (optional) take the start / end timestamps of this dispatch itself: no separate
     // event packets, hence no bubbles around the kernel when it is being timed
+    if constexpr (W == 1 && FN == 256) {
+        if (uni.queue && uni.q_grid) {
+            ResidentArgs ra;
+            ra.samples = samples; ra.frames = frames; ra.ids = ids; ra.plans = plans; ra.twpool = twpool; ra.prm = prm;
+            ra.slots = slots; ra.res = res; ra.diag = diag; ra.uni = uni; ra.queue = uni.queue;
+            ra.count = count;
+            hipExtLaunchKernelGGL((k_compress_resident<W, SPL, IDW, FN, LEAN_>), dim3(uni.q_grid), dim3(64 * W), lds, s, ev0, ev1, 0, ra);
+            return hipGetLastError();
+        }
+    }
     hipExtLaunchKernelGGL(kern, dim3(count), dim3(64 * W), lds, s, ev0, ev1, 0, samples, frames, ids,
                           plans, twpool, prm, slots, res, diag, uni);
     return hipGetLastError();
+}
+
+uint32_t resident_grid(int cls, uint32_t n, uint32_t lds)
+{
+    if (cls != 1 || n != 256) return 0;
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_compress_resident<1, 5, false, 256>, 64, lds) != hipSuccess || nb <= 0)
+            return 0;
+        if (const char *e = getenv("ATSC_RESIDENT_PER_CU")) nb = atoi(e);
+        per_cu = nb;
+        cus = pr.multiProcessorCount;
+    }
+    return (uint32_t)(per_cu * cus);
 }
 
 template <int W, int SPL>

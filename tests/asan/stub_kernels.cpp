@@ -20,6 +20,7 @@ hipError_t launch_compress_large(uint32_t, const double *, const DevFrame *, con
 {
     return hipErrorNotSupported;
 }
+uint32_t resident_grid(int, uint32_t, uint32_t) { return 0; }
 // same bound as atsc_large.hip needs is irrelevant here: the parser only takes the maximum
 uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap) { return 64ull * n + 32ull * L + 16ull * kcap; }
 hipError_t launch_decompress_large(uint32_t, const struct DevDFrame *, const uint32_t *, const DevPlan *,

@@ -62,6 +62,13 @@ a = a[ok]
 t0 = a[:, 0].min()
 beg, end = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
 hw = a[:, 2]
+if os.environ.get("DUMP_LONG"):
+    idx = np.nonzero(ok)[0]
+    life = end - beg
+    o = np.argsort(-life)[:40]
+    for k in o:
+        print("   long frame: launch slot %6d  class block %d  start %7.1f  end %7.1f  life %6.1f  cu %d" % (
+            idx[k], (idx[k] // 256) % 5, beg[k], end[k], life[k], (int(hw[k]) >> 8) & 0xF))
 print("launch spans %.1f us; %d frames with both stamps; frame life mean %.2f us, p50 %.2f, p99 %.2f, max %.2f" % (
     end.max(), len(a), (end - beg).mean(), np.median(end - beg), np.percentile(end - beg, 99), (end - beg).max()))
 for t in range(0, int(end.max()) + 1, 8):
