@@ -26,6 +26,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime deals streams over a handful of hardware queues (four by default); a chain of the pipelined entry
+# point that shares its queue with another stream's dependent work stalls behind it ("Several
+# chains").  Eight queues leave room for the chains beside PyTorch's and the communicator's streams.  Read by the
+# runtime when it starts, so it is set before anything imports torch; a value the caller set wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_SAMPLES = 10485760
 FRAME = 256
@@ -673,6 +678,7 @@ def main():
                                 "cost order (clocks of the same slot in an earlier batch of the chain -- a batch with "
                                 "another class layout)"))
                             if pipelined else "single stream, plain calls",
+                "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
             },
         }
         if world > 1:

@@ -17,13 +17,15 @@ def first(pattern):  # the newest match: gpurun merges every call's files into t
 f = first(os.path.join(G, tag + "_stats", "*", "*kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
-for name in ("bench", "bench_chains", "stats_bench", "bench_share2"):
+for name in ("bench", "bench_chains", "bench_chains1", "bench_chains4", "stats_bench", "bench_share2"):
     src = os.path.join(G, "%s_%s.json" % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
         if lines:
             open(os.path.join(P, "%s_%s.json" % (tag, name)), "w").write(lines[-1] + "\n")
-for name in ("other_configs", "config3_full_1gpu", "length_probe", "stamps_256", "stamps_2048", "stamps_4096", "queue_probe"):
+for name in ("other_configs", "config3_full_1gpu", "length_probe", "stamps_256", "stamps_2048", "stamps_4096", "queue_probe",
+             "chain_stamps_1", "chain_stamps_2", "resident_ab", "dispatch_probe", "gap_probe", "host_path", "large_decode_probe",
+             "large80_decode_kernels", "large_ties"):
     src = os.path.join(G, "%s_%s.txt" % (tag, name))
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().splitlines() if "amdgpu.ids" not in l)
