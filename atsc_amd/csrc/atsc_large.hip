@@ -396,6 +396,7 @@ DEVI uint32_t lscan(uint32_t *arr, uint32_t count, uint32_t *wsum)
 constexpr uint32_t SPB = 8;          // output columns per LDS tile
 constexpr uint32_t SP_MF_MAX = 992;  // longest LDS sub-transform (host: DevPlan::sp_mf)
 constexpr uint32_t SP_MD_MAX = 256;
+constexpr uint32_t RLE_LDS_RUNS = 6144;  // runs k_decompress_large<0> sorts and expands from LDS (2 x 48 KB)
 constexpr uint32_t SP_LDS_BYTES = (2 * SPB * SP_MF_MAX + SP_MF_MAX + SP_MD_MAX) * 8 + (2 * SP_MF_MAX + 8) * 4;
 
 struct SpEnt {
@@ -2743,6 +2744,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
                 }
             }
             h.u0 = e;
+            h.u1 = (uint32_t)groups;
             break;
         }
         default: r.bad = true;
@@ -3001,6 +3003,30 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
         const uint32_t E = h.u0;
         uint32_t p2 = 1;
         while (p2 < E) p2 <<= 1;
+        if (PH == 0 && E >= 1 && E <= RLE_LDS_RUNS && h.u1 <= RLE_LDS_RUNS) {
+            // Up to RLE_LDS_RUNS runs (a 131072-sample frame of a slowly changing gauge has about a thousand): the run
+            // starts are sorted in LDS and every run is written by one wavefront, 64 samples a store, its value read
+            // once -- instead of a sort in the workspace and a binary search of it per sample (ten dependent L2 round
+            // trips for each of the frame's samples: 530 us for six such frames).  Runs that share a start keep the
+            // reference's outcome: sorted by (start, group), all but the last of them are empty.
+            uint64_t *lk = (uint64_t *)(smem + 256 + STG_BYTES);
+            double *lv = (double *)(lk + RLE_LDS_RUNS);
+            for (uint32_t i = tid; i < E; i += T) lk[i] = keys[i];
+            for (uint32_t i = tid; i < h.u1; i += T) lv[i] = vals[i];
+            __syncthreads();
+            block_sort<LW, true>(lk, nullptr, E, p2);
+            const uint32_t first = (uint32_t)(lk[0] >> 32);
+            for (uint32_t j = tid; j < first; j += T) out[j] = 0.0;
+            const uint32_t lane = tid & 63u;
+            for (uint32_t i = tid >> 6; i < E; i += LW) {
+                const uint64_t k = lk[i];
+                const uint32_t start = (uint32_t)(k >> 32);
+                const uint32_t end = (i + 1 < E) ? (uint32_t)(lk[i + 1] >> 32) : n;
+                const double v = lv[(uint32_t)(k & 0xffffffffu)];
+                for (uint32_t j = start + lane; j < end; j += 64) out[j] = v;
+            }
+            return;
+        }
         block_sort<LW, true>(keys, nullptr, E, p2);
         for (uint32_t j = tid; j < n; j += T) {
             uint32_t lo = 0, hi = E;
