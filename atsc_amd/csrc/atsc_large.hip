@@ -2481,7 +2481,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         if (e != hipSuccess) return e;
     }
     // The fast path (atsc_large_fast.h): frames of 131072 samples under the auto selector, any number of them.
-    static const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;
+    const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;  // (read per launch: the tests switch it)
     const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p == 32 && pre->chunks_n && kp.sparse_inv &&
                       kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
                       (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
@@ -3135,7 +3135,7 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             const int sp_split = (sparse && sp_tiles && count <= LARGE_SPLIT_MAX) ? 1 : 0;
             // FFT frames of 131072 samples: k_large_dparse + the tile grid (atsc_large_fast.h); the rest, and whatever
             // the parser leaves alone, behind them
-            static const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;
+            const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;  // (read per launch: the tests switch it)
             const int fast = (!no_fast && sparse && pre && pre->cols243 && pre->rows9p == 32) ? 1 : 0;
             if (fast) {
                 e = ensure_dyn_lds((const void *)k_large_dparse, FAST_DP_LDS);

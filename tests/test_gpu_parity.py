@@ -1126,6 +1126,45 @@ def test_large_frames_grid_and_single_kernel_forms_agree(ctx, A, monkeypatch):
         assert np.array_equal(out_g, out_1, equal_nan=True)
 
 
+def test_large_fast_path_matches_general_kernel(ctx, A, oracle, monkeypatch):
+    """131072-sample frames under the auto selector take the grid path of atsc_large_fast.h (column / row transforms
+    in registers, per-frame decisions as their own launches, the tile kernel for the first ladder trip and for the
+    decoder); ATSC_LARGE_NO_FAST keeps the general per-frame kernels.  Two forward transforms with different
+    butterfly orders: the coefficients agree to f32 accuracy, so the two forms must choose the same codecs with
+    the same K, report the same error to the decode bar's accuracy, and both decoders must reproduce the oracle's
+    decode of either stream (polynomial / RLE / constant frames bit for bit)."""
+    F = 131072
+    xs = [H.synth_series(1500 + c, 2 * F, klass=c) for c in (0, 1, 2, 3, 4)]
+    x = np.concatenate(xs)
+    off = H.frame_offsets(len(x), F)
+    nf = len(off) - 1
+    for me in (ME5, ME1):
+        monkeypatch.delenv("ATSC_LARGE_NO_FAST", raising=False)
+        rec_f, _, ch_f, err_f = ctx.compress_host(x, off, A.AUTO, True, me, 0)
+        out_ff = ctx.decompress_host(rec_f)
+        monkeypatch.setenv("ATSC_LARGE_NO_FAST", "1")
+        rec_g, _, ch_g, err_g = ctx.compress_host(x, off, A.AUTO, True, me, 0)
+        out_fg = ctx.decompress_host(rec_f)  # the fast path's stream through the general decoder
+        monkeypatch.delenv("ATSC_LARGE_NO_FAST", raising=False)
+        assert np.array_equal(ch_f, ch_g), (me, ch_f, ch_g)
+        ff = H.parse_bro_body(rec_f, with_count=False)
+        fg = H.parse_bro_body(rec_g, with_count=False)
+        ref = np.array(oracle.decompress_data(A.bro_prefix(nf) + rec_f))
+        for i in range(nf):
+            seg = slice(int(off[i]), int(off[i + 1]))
+            if ch_f[i] == oracle.FFT:
+                ka, kb = H.parse_fft_payload(ff[i][3])[0], H.parse_fft_payload(fg[i][3])[0]
+                assert len(ka) == len(kb), (me, i, len(ka), len(kb))
+                tol = P.FFT_ERR_ATOL + P.FFT_ERR_RTOL * abs(err_g[i]) + P.fft_err_noise(x[seg])
+                assert abs(err_f[i] - err_g[i]) <= tol, (me, i, err_f[i], err_g[i])
+                scale = max(np.max(np.abs(ref[seg])), 1e-30)
+                t = (4 + np.log2(F)) * scale * 2.0 ** -23 + 1.00001e-5
+                assert np.max(np.abs(out_ff[seg] - ref[seg])) <= t and np.max(np.abs(out_fg[seg] - ref[seg])) <= t, (me, i)
+            else:
+                assert ff[i] == fg[i], (me, i)
+                assert np.array_equal(out_ff[seg], ref[seg]) and np.array_equal(out_fg[seg], ref[seg]), (me, i)
+
+
 # ---------------------------------------------------------------------------------------
 # Bins of equal norm: the admission order is the reference's BinaryHeap pop order (fft.rs:231-257)
 # ---------------------------------------------------------------------------------------
