@@ -270,6 +270,9 @@ __device__ unsigned long long g_frame_span[4 * 65536 * 3];  // wall clock (100 M
 // geometry is folded at compile time; FN == 0 reads it from the per-length table.
 DEVI void frame_prio(uint32_t trips)  // (s_setprio takes an immediate)
 {
+#ifndef ATSC_FRAME_PRIO  // off: measured 1-2 % slower for the one-workgroup-per-frame launch (below)
+    return;
+#endif
     if (trips == 3) __builtin_amdgcn_s_setprio(1);
     else if (trips == 7) __builtin_amdgcn_s_setprio(2);
     else if (trips == 12) __builtin_amdgcn_s_setprio(3);
@@ -286,12 +289,13 @@ __device__ __forceinline__ void compress_frame(
     constexpr bool FIX_ = FN != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = tid_now<W>();  // (opaque: see tid_now)
-    // Issue priority follows the frame's age in ladder trips (frame_prio below): a frame that is still going after
-    // several trips is one of the launch's long ones, and the sooner those end the shorter the launch's tail.  It
-    // matters most for resident workgroups (k_compress_resident): their wavefronts were all started together, so
-    // the hardware's oldest-first arbitration ranks them once and for all, and the last of a SIMD's five would take
-    // 100 us and more over a frame that takes 15.
+    // (-DATSC_FRAME_PRIO: issue priority follows the frame's age in ladder trips, frame_prio above.  It exists for
+    // resident workgroups -- k_compress_resident: their wavefronts were all started together, the hardware's oldest-first
+    // arbitration ranks them once and for all, and the last of a SIMD's five took 100 us and more over a frame that
+    // takes 15 -- and costs the per-frame grid 1-2 %: 97.3 vs 99.2 Gsamples/s, configs[3] 58.3 vs 58.8.)
+#ifdef ATSC_FRAME_PRIO
     if (W == 1) __builtin_amdgcn_s_setprio(0);
+#endif
     uint32_t fid;
     DevFrame fr;
     const long long t_start = prm.cost ? clock64() : 0;

@@ -280,7 +280,7 @@ ROTATE = 5          # resident batches the timed loop cycles through (N = 1 work
 C3_SERIES = 4096    # configs[3]: 4096 series x 262144 samples = 2^30
 C3_PER = 262144
 C3_ERROR_PCT = 1
-C3_ROTATE = 2       # resident batches per rank at N > 1 (different series values, same shape)
+C3_ROTATE = 3       # resident batches per rank for configs[3] (different series values, same classes); coprime with the 4 scratch sets
 XGMI_LINK_GBS = 70.0  # per-direction rate of one xGMI link assumed by --root-weight auto
 
 
@@ -299,6 +299,7 @@ def main():
                          "(atsc_compress_plan_dev_pipelined)")
     ap.add_argument("--chains", type=int, default=0, help="chains of the pipelined entry point (1..4; 0: the library's default, 2)")
     ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
+    ap.add_argument("--no-adaptive-order", action="store_true", help="configs[3] workload: frames in index order (see --adaptive-order)")
     ap.add_argument("--adaptive-order", action="store_true",
                     help="start the frames costliest-first instead of in index order (cost = shader clocks of the same "
                          "frame slot in an earlier batch of the same chain); off by default: with two chains in flight the "
@@ -352,6 +353,11 @@ def main():
     ctx = atsc_amd.Context(dev_index)
     if args.chains:
         ctx.set_chains(args.chains)
+    # configs[3]: a series keeps its class from batch to batch (slot i = the same series one window later), which is
+    # the recurring layout the cost hint is for, and C3_ROTATE is coprime with the scratch sets in rotation, so the
+    # hint a step uses always comes from ANOTHER resident batch (other values of the same series): on unless asked not to
+    if workload == "config3" and not args.no_adaptive_order:
+        args.adaptive_order = True
     ctx.set_adaptive_order(bool(args.adaptive_order))
     root_weight = 1.0
     if workload == "config2":
@@ -675,8 +681,10 @@ def main():
                              "context's own, two scratch sets each); frames start in %s"
                              % (args.chains or "the default 2",
                                 "index order (no cost hint)" if not args.adaptive_order else
-                                "cost order (clocks of the same slot in an earlier batch of the chain -- a batch with "
-                                "another class layout)"))
+                                ("cost order (clocks of the same slot in an earlier batch of the chain -- another resident "
+                                 "batch: other values of the same series, same class)" if workload == "config3" else
+                                 "cost order (clocks of the same slot in an earlier batch of the chain -- a batch with "
+                                 "another class layout)")))
                             if pipelined else "single stream, plain calls",
                 "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
             },
