@@ -157,7 +157,9 @@ int atsc_ctx_set_chains(atsc_ctx *ctx, int n);
 /* Pipelined calls record how many shader clocks every frame took and start the next batches of the
  * same plan with a class's costliest frames first (frame i of a recurring batch is the same series,
  * one window later); otherwise the frames that run longest start last and the GPU drains half
- * empty.  Only the order of execution changes, never a result.  On by default; 0 turns it off. */
+ * empty.  Only the order of execution changes, never a result.  OFF by default since round 3 (with two chains in
+ * flight the next batch's first frames fill the drain the order was there to shorten, and the hint only predicts
+ * where the layout recurs -- slot i the same series with the same behaviour, batch after batch); 1 turns it on. */
 int atsc_ctx_set_adaptive_order(atsc_ctx *ctx, int on);
 /* Makes `stream` wait (device side, no host block) for every batch enqueued so far by
  * atsc_compress_plan_dev_pipelined on `plan`: its records are packed. */
