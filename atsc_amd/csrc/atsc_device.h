@@ -167,6 +167,23 @@ DEVI uint32_t dpp_u32(uint32_t v)  // lanes without a source read 0
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
 }
+// value of lane `l` (a compile-time lane) in every lane
+DEVI double lane_f64(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// lane i receives lane i - 1's value (whole wavefront: DPP wave_shr:1); lane 0 keeps its own
+DEVI double wave_shr1_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(uint32_t)b, hi = (int)(uint32_t)((unsigned long long)b >> 32);
+    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)h2 << 32) | l2));
+}
 template <int CTRL, int ROWMASK>
 DEVI uint32_t dpp_u32_keep(uint32_t v, uint32_t ident)
 {

@@ -374,11 +374,54 @@ __device__ __forceinline__ void compress_frame(
     int mode = LEAN ? (int)ATSC_AUTO : prm.mode;
     const bool bounded = LEAN ? true : (prm.bounded != 0);
 
+    constexpr bool REGSTAT = FIX && W == 1 && (FN == 256 || FN == 512);  // (128: the extra state spills)
+    bool reg_stats = false;
+    double rs_mn = 0.0, rs_mx = 0.0;
+    uint32_t rs_frac = 0, rs_pk = 0;
     // ---- load samples (the twiddles follow when the FFT candidate starts: until then and after
     // its ladder their region hosts `aux` and the RLE group table) ----------------------------
     {
         const double *src = samples + fr.sample_off;
-        if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
+        if constexpr (REGSTAT) {
+            if ((fr.sample_off & 1ull) == 0) {
+                // One-wavefront frames of a fixed even length: the lane's pairs stay in registers for the statistics
+                // and the RLE bound (run starts and their index bytes), which so need neither the LDS round trips of
+                // reading the samples back (4 + 8 per lane at n = 256) nor the barrier in front of them.  A sample's
+                // left neighbour is the pair's other half, or the lane before's second half (DPP wave_shr:1), or --
+                // lane 0 -- the last lane's second half of the chunk before (v_readlane).
+                constexpr int NP = FN / 128;  // pairs per lane
+                const double2 *src2 = (const double2 *)src;
+                double2 *xs2 = (double2 *)xs;
+                double2 v[NP];
+#pragma unroll
+                for (int m = 0; m < NP; ++m) v[m] = src2[tid + 64 * m];
+#pragma unroll
+                for (int m = 0; m < NP; ++m) xs2[tid + 64 * m] = v[m];
+                const double x0 = lane_f64(v[0].x, 0);
+                rs_mn = x0;
+                rs_mx = x0;
+#pragma unroll
+                for (int m = 0; m < NP; ++m) {
+                    const double a = v[m].x, b = v[m].y;
+                    rs_frac |= (frac_nonzero(a) || frac_nonzero(b)) ? 1u : 0u;
+                    if (a > rs_mx) rs_mx = a;
+                    if (a < rs_mn) rs_mn = a;
+                    if (b > rs_mx) rs_mx = b;
+                    if (b < rs_mn) rs_mn = b;
+                    double left = wave_shr1_f64(b);                     // lane - 1's second half
+                    if (m > 0) {
+                        const double wrap = lane_f64(v[m - 1].y, 63);   // (uniform)
+                        left = (tid == 0) ? wrap : left;
+                    }
+                    const uint32_t jx = 2u * (tid + 64u * (uint32_t)m);
+                    if (jx == 0 || a != left) rs_pk += (vlen(jx) << 13) | 1u;
+                    if (b != a) rs_pk += (vlen(jx + 1) << 13) | 1u;
+                }
+                reg_stats = true;
+            }
+        }
+        if (reg_stats) {
+        } else if (((fr.sample_off | n) & 1ull) == 0) {  // 16 B per lane when the frame is 16-B aligned
             const double2 *src2 = (const double2 *)src;
             double2 *xs2 = (double2 *)xs;
             for_strided<FN / 2, T, (SPL + 1) / 2>(tid, n >> 1, [&](uint32_t j) { xs2[j] = src2[j]; });
@@ -394,15 +437,20 @@ __device__ __forceinline__ void compress_frame(
     double smin, smax;
     uint32_t bitdepth;
     {
-        const double x0 = xs[0];
-        double mn = x0, mx = x0;
+        double mn, mx;
         uint32_t fr_any = 0;
-        for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
-            const double v = xs[j];
-            fr_any |= frac_nonzero(v) ? 1u : 0u;
-            if (v > mx) mx = v;
-            if (v < mn) mn = v;
-        });
+        if (reg_stats) {
+            mn = rs_mn; mx = rs_mx; fr_any = rs_frac;
+        } else {
+            const double x0 = xs[0];
+            mn = x0; mx = x0;
+            for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
+                const double v = xs[j];
+                fr_any |= frac_nonzero(v) ? 1u : 0u;
+                if (v > mx) mx = v;
+                if (v < mn) mn = v;
+            });
+        }
         mn = block_minmax_f64<W, true>(mn, red, parity);
         mx = block_minmax_f64<W, false>(mx, red, parity);
         fr_any = block_or_u32<W>(fr_any, red, parity);
@@ -648,10 +696,14 @@ __device__ __forceinline__ void compress_frame(
     if (run_rle) {
         // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
         uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
-        for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
-            const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
-            if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
-        });
+        if (reg_stats) {
+            pk = rs_pk;  // counted from the registers the samples arrived in
+        } else {
+            for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
+                const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
+                if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
+            });
+        }
         pk = block_sum_u32<W>(pk, red, parity);
         rle_R = pk & 0x1fffu;
         rle_ib = pk >> 13;
