@@ -57,7 +57,15 @@ static const int N_CLASSES = 7;       // 0..5: LDS-resident frame kernels, 6: la
 static const int CLASS_LARGE = 6;
 static const uint32_t MAX_FRAME_TIER_M = 4096;   // longest frame of the LDS-resident kernels
 static const uint32_t MAX_FRAME = 131072;        // MAX_FRAME_SIZE of the reference chunker (optimizer/mod.rs:27)
-static const uint32_t LARGE_WS_SLOTS = 256;      // large frames in flight (one workgroup + workspace each)
+static const uint32_t LARGE_WS_SLOTS = 256;      // large frames in flight (one workgroup + workspace each) ...
+// ... of the longest kind; a batch of shorter large frames gets as many slots as the same memory holds (a launch of 256
+// 8192-sample frames is 2 M samples: every grid of the large tier would be latency-bound on it)
+static uint32_t large_ws_slots(uint64_t ws_stride)
+{
+    const uint64_t budget = 800ull << 20;
+    const uint64_t fit = ws_stride ? budget / ws_stride : LARGE_WS_SLOTS;
+    return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(LARGE_WS_SLOTS, fit));
+}
 
 struct atsc_ctx {
     int device = 0;
@@ -316,7 +324,7 @@ static bool large_sparse() { return getenv("ATSC_LARGE_DENSE") == nullptr; }
 static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::vector<uint32_t> &large_plan_ids)
 {
     LargePre pre{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool first_large = true;
+    bool first_large = true, rows_ok = true;
     if (getenv("ATSC_LARGE_NO_PREPASS")) return pre;
     pre.cols243 = getenv("ATSC_LARGE_OLD_COLS") ? 0u : 1u;
     for (uint32_t pi : large_plan_ids) {
@@ -330,10 +338,17 @@ static LargePre large_pre_extents(const std::vector<DevPlan> &plans, const std::
         if (p.sp_mf) pre.sp_tiles = std::max(pre.sp_tiles, (p.sp_md + 7) / 8);
         pre.chunks_n = std::max(pre.chunks_n, (p.n + 4095) / 4096);
         if (p.f4_m1 != 243) pre.cols243 = 0;
-        const uint32_t rp = (p.f4_m1 == 243 && p.f4_m2 == 288 && !getenv("ATSC_LARGE_OLD_ROWS")) ? 32u : 0u;
-        pre.rows9p = first_large ? rp : (pre.rows9p == rp ? rp : 0u);
+        // rows9p: the set of P (as a bit mask) over the large frames when EVERY one of them has M = 243 x 9 P, else 0
+        uint32_t rp = 0;
+        if (p.f4_m1 == 243 && p.f4_m2 % 9 == 0 && !getenv("ATSC_LARGE_OLD_ROWS")) {
+            const uint32_t P9 = p.f4_m2 / 9;
+            if (P9 >= 2 && P9 <= 32 && (P9 & (P9 - 1)) == 0) rp = P9;
+        }
+        pre.rows9p = (rp && (first_large || pre.rows9p)) ? (pre.rows9p | rp) : 0u;
+        if (!rp) rows_ok = false;
         first_large = false;
     }
+    if (!rows_ok) pre.rows9p = 0;
     if (getenv("ATSC_LARGE_NO_TRIP_TILES")) pre.sp_tiles = 0;
     return pre;
 }
@@ -449,6 +464,13 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
         uint32_t d = (uint32_t)std::sqrt((double)p.M);
         while (d > 1 && p.M % d != 0) --d;
         if (d > 1 && p.M / d <= 480) { p.f4_m1 = d; p.f4_m2 = p.M / d; }
+        // M = 243 x 9 P, P = 2 .. 32 a power of two -- every power-of-two frame length from 8192 to 131072 samples (the
+        // reference chunker's chunks, L = 2^a 3^7): the split the register-resident column / row transforms and the
+        // large tier's grid path are written for (k_large_cols243, k_large_rows9p<P>, atsc_large_fast.h)
+        if (p.half && p.M % (243u * 9u) == 0) {
+            const uint32_t P9 = p.M / (243u * 9u);
+            if (P9 >= 2 && P9 <= 32 && (P9 & (P9 - 1)) == 0 && !getenv("ATSC_LARGE_SQRT_SPLIT")) { p.f4_m1 = 243; p.f4_m2 = 9 * P9; }
+        }
     }
     p.sp_mf = p.sp_md = 0;
     if (!p.direct && p.M >= 1024) {
@@ -847,7 +869,7 @@ extern "C" int atsc_plan_create(atsc_ctx *ctx, const uint64_t *frame_off, uint64
     PCHK(pool_alloc(ctx, (void **)&p->d_blocksum, (nb + 1) * sizeof(uint64_t)));
     if (p->class_count[CLASS_LARGE]) {
         // (a multiple of 4: the groups of a call get equal shares of the slots)
-        p->ws_slots = (std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS) + 3u) & ~3u;
+        p->ws_slots = (std::min<uint32_t>(p->class_count[CLASS_LARGE], large_ws_slots(p->ws_stride)) + 3u) & ~3u;
         PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK
@@ -1918,7 +1940,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
     PCHK(pool_alloc(ctx, (void **)&p->d_status, sizeof(int)));
     PCHK(hipMemset(p->d_status, 0, sizeof(int)));
     if (p->class_count[CLASS_LARGE]) {
-        p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], LARGE_WS_SLOTS);
+        p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], large_ws_slots(p->ws_stride));
         PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK

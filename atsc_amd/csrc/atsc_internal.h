@@ -136,7 +136,8 @@ struct LargePre {
     uint32_t sp_tiles;                // most tiles (8 output columns each) the sparse inverse of a frame has
     uint32_t chunks_n;                // most 4096-sample chunks a frame has (k_large_stats, k_large_poly1)
     uint32_t cols243;                 // 1: every large frame length splits as M = 243 x M2 (k_large_cols243)
-    uint32_t rows9p;                  // P when every large frame length has M2 = 9 P, P = 32 (k_large_rows9p), else 0
+    uint32_t rows9p;                  // when every large frame length has M = 243 x 9 P, P = 2 .. 32 a power of two: the
+                                      // P values present, as a bit mask (k_large_rows9p<P>); else 0
     uint32_t even_off;                // 1: every large frame starts on an even sample (16-byte pairs, given an aligned base)
 };
 constexpr uint32_t LARGE_SPLIT_MAX = 128;  // large frames per launch up to which the first FFT trip's tiles

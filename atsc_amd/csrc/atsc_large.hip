@@ -2442,6 +2442,39 @@ __global__ __launch_bounds__(LT) void k_large_trip_tiles(
 constexpr uint32_t STG_BYTES = 16384;  // payload window of the large decoder (RdS, atsc_device.h)
 #include "atsc_large_fast.h"
 
+// k_large_trip243 for every row dimension present among the launch's frames (LargePre::rows9p holds the P = 2^LG values)
+template <bool DECODE, class FR>
+static hipError_t launch_trip243(uint32_t pmask, uint32_t tiles, uint32_t nb, hipStream_t s, const double *samples, const FR *frames,
+                                 const uint32_t *ids, const DevPlan *plans, const float2 *twpool, unsigned char *ws,
+                                 uint64_t ws_stride, int dbg, double *out)
+{
+#define ATSC_TRIP(LG_)                                                                                                        \
+    if (pmask & (1u << LG_)) {                                                                                                 \
+        hipError_t e = ensure_dyn_lds((const void *)k_large_trip243<DECODE, FR, LG_>, FAST_TILE_LDS);                          \
+        if (e != hipSuccess) return e;                                                                                         \
+        hipLaunchKernelGGL((k_large_trip243<DECODE, FR, LG_>), dim3(min(tiles, (9u << LG_) / 16u + (((9u << LG_) & 15u) ? 1u : 0u)), nb), \
+                           dim3(CT), FAST_TILE_LDS, s, samples, frames, ids, plans, twpool, ws, ws_stride, dbg, out);          \
+    }
+    ATSC_TRIP(5) ATSC_TRIP(4) ATSC_TRIP(3) ATSC_TRIP(2) ATSC_TRIP(1)
+#undef ATSC_TRIP
+    return hipSuccess;
+}
+
+// The row pass of every P present among the launch's frames (LargePre::rows9p): one launch per P, whose workgroups
+// leave the frames of another P alone; the polynomial pieces of a frame (extra workgroups behind the row tiles) ride on
+// the launch of the frame's own P.
+static void launch_rows9p(uint32_t pmask, uint32_t row_tiles, uint32_t pieces, uint32_t nb, hipStream_t s, const double *samples,
+                          const DevFrame *frames, const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
+                          unsigned char *ws, uint64_t ws_stride, int sparse_inv)
+{
+    const dim3 g(row_tiles + pieces, nb);
+    if (pmask & 32u) hipLaunchKernelGGL(k_large_rows9p<32>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+    if (pmask & 16u) hipLaunchKernelGGL(k_large_rows9p<16>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+    if (pmask & 8u) hipLaunchKernelGGL(k_large_rows9p<8>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+    if (pmask & 4u) hipLaunchKernelGGL(k_large_rows9p<4>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+    if (pmask & 2u) hipLaunchKernelGGL(k_large_rows9p<2>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+}
+
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool,
                                  const KParams &prm, uint8_t *slots, DevResult *res, atsc_frame_diag *diag,
@@ -2482,13 +2515,11 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     }
     // The fast path (atsc_large_fast.h): frames of 131072 samples under the auto selector, any number of them.
     const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;  // (read per launch: the tests switch it)
-    const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p == 32 && pre->chunks_n && kp.sparse_inv &&
+    const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p != 0 && pre->chunks_n && kp.sparse_inv &&
                       kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
                       (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
     if (fast) {
         e = ensure_dyn_lds((const void *)k_large_decide1, FAST_D1_LDS);
-        if (e != hipSuccess) return e;
-        e = ensure_dyn_lds((const void *)k_large_trip243<false, DevFrame>, FAST_TILE_LDS);
         if (e != hipSuccess) return e;
         e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
         if (e != hipSuccess) return e;
@@ -2513,18 +2544,19 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             }
             kp.tile_stats = tst ? 1u : 0u;
             if (tst) {  // the row pass and the first polynomial trip's pieces in one launch
-                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23 + pre->chunks_n * (LCH / PCH), nb), dim3(RT), 0, s, samples,
-                                   frames, ids + b0, plans, twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
+                launch_rows9p(pre->rows9p, tiles23, pre->chunks_n * (LCH / PCH), nb, s, samples, frames, ids + b0, plans, twpool,
+                              ws, ws_stride, (int)kp.sparse_inv);
             } else {
                 hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
                                    ws, ws_stride, 0);
-                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
-                                   twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
+                launch_rows9p(pre->rows9p, tiles23, 0, nb, s, samples, frames, ids + b0, plans, twpool, ws, ws_stride,
+                              (int)kp.sparse_inv);
             }
             hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), FAST_D1_LDS, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, ws, ws_stride);
-            hipLaunchKernelGGL((k_large_trip243<false, DevFrame>), dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s, samples,
-                               frames, ids + b0, plans, twpool, ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
+            e = launch_trip243<false, DevFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, samples, frames, ids + b0, plans, twpool,
+                                                ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
+            if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_large_decide2, dim3(nb), dim3(LT), FAST_D2_LDS, s, samples, frames, ids + b0, plans, kp,
                                slots, res, ws, ws_stride);
             // whatever those left undecided (FastState::status != 2)
@@ -2552,9 +2584,9 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                 hipLaunchKernelGGL((k_large_pre1<DevFrame, false>), dim3(pre->tiles1, nb), dim3(PT), lds1, s, samples,
                                    frames, ids + b0, plans, twpool, ws, ws_stride);
             const uint32_t tiles23 = 1 + ((pre->m1_max - 1) / 2 + FBH - 1) / FBH;
-            if (pre->cols243 && pre->rows9p == 32)
-                hipLaunchKernelGGL(k_large_rows9p<32>, dim3(tiles23, nb), dim3(RT), 0, s, samples, frames, ids + b0, plans,
-                                   twpool, ws, ws_stride, (int)kp.sparse_inv, tiles23);
+            if (pre->cols243 && pre->rows9p != 0)
+                launch_rows9p(pre->rows9p, tiles23, 0, nb, s, samples, frames, ids + b0, plans, twpool, ws, ws_stride,
+                              (int)kp.sparse_inv);
             else
                 hipLaunchKernelGGL(k_large_pre23, dim3(tiles23, nb), dim3(PT), lds2, s, samples, frames, ids + b0, plans,
                                    twpool, ws, ws_stride, (int)kp.sparse_inv);
@@ -3136,17 +3168,16 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
             // FFT frames of 131072 samples: k_large_dparse + the tile grid (atsc_large_fast.h); the rest, and whatever
             // the parser leaves alone, behind them
             const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;  // (read per launch: the tests switch it)
-            const int fast = (!no_fast && sparse && pre && pre->cols243 && pre->rows9p == 32) ? 1 : 0;
+            const int fast = (!no_fast && sparse && pre && pre->cols243 && pre->rows9p != 0) ? 1 : 0;
             if (fast) {
                 e = ensure_dyn_lds((const void *)k_large_dparse, FAST_DP_LDS);
-                if (e != hipSuccess) return e;
-                e = ensure_dyn_lds((const void *)k_large_trip243<true, DevDFrame>, FAST_TILE_LDS);
                 if (e != hipSuccess) return e;
                 static const int dbg = getenv("ATSC_DEBUG_DPARSE") ? 1 : 0;
                 hipLaunchKernelGGL(k_large_dparse, dim3(nb), dim3(LT), FAST_DP_LDS, s, frames, ids + b0, plans, twpool, body,
                                    ws, ws_stride, dbg);
-                hipLaunchKernelGGL((k_large_trip243<true, DevDFrame>), dim3(FAST_TILES, nb), dim3(CT), FAST_TILE_LDS, s,
-                                   (const double *)nullptr, frames, ids + b0, plans, twpool, ws, ws_stride, 0, out);
+                e = launch_trip243<true, DevDFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, (const double *)nullptr, frames, ids + b0,
+                                                    plans, twpool, ws, ws_stride, 0, out);
+                if (e != hipSuccess) return e;
             }
             hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
                                body, out, status, ws, ws_stride, tiled, sparse, sp_split, fast);

@@ -412,13 +412,15 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
                                                       int sparse_inv, uint32_t row_tiles)
 {
     constexpr uint32_t M2 = 9 * P, BS = P + 1, ZS = M2 + 1;
-    constexpr uint32_t NPT = (FB * 9 * BS > FB * ZS) ? FB * 9 * BS : FB * ZS;
+    constexpr uint32_t NPT0 = (FB * 9 * BS > FB * ZS) ? FB * 9 * BS : FB * ZS;
+    constexpr uint32_t NPT = NPT0 > 2112 ? NPT0 : 2112;  // (the polynomial pieces borrow the tile buffer: 16.5 KB)
     __shared__ float2 w2[M2];
     __shared__ __attribute__((aligned(16))) float2 T[NPT];
     static_assert(NPT * 8 >= 8192 + 16 * 512 + 512, "the polynomial pieces borrow the tile buffer (basis, tangents, 48 doubles)");
     const DevPlan *Pl;
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, Pl);
     if (blockIdx.x >= row_tiles) {  // workgroups behind the row tiles: pieces of the first polynomial trip
+        if (f.M2 != 9 * P) return;  // (another launch's frame)
         poly1_piece(f.xs, *Pl, f.ws, large_ws_layout(f.n, f.L, Pl->kcap), blockIdx.x - row_tiles, (unsigned char *)T);
         return;
     }

@@ -21,12 +21,40 @@
 // Pruning is the selector's own arithmetic (a ladder's payload only grows, so a ladder stops once its next payload
 // cannot beat a candidate that already passes): the winner and its bytes are the reference's.
 
-constexpr uint32_t FAST_MF = 243, FAST_MD = 288, FAST_TILES = FAST_MD / 16;
+constexpr uint32_t FAST_MF = 243, FAST_MD = 288;  // FAST_MD: the widest row dimension (131072 samples)
 constexpr uint32_t FAST_CAND_MAX = 6144;   // candidates of the threshold digit held in LDS
 constexpr uint32_t FAST_K_MAX = 1344;      // K1 <= mf = n / 100 = 1310
 constexpr uint32_t FAST_OWN = 4608;        // positions below bins - 65536 = 4449 can collide after `pos as u16`
-constexpr uint32_t FAST_LIST_OFF = 0, FAST_BOUNDS_OFF = 65536, FAST_KEYS_OFF = 69632;  // inside buffer B
+constexpr uint32_t FAST_LIST_OFF = 0;        // inside buffer B: the list, then the bucket bounds, then the sort keys
 constexpr uint32_t FAST_PARTIAL_OFF = 8192;  // inside buffer C (as TRIP_PARTIAL_OFF)
+
+// Geometry of a frame this path serves: M = 243 x md, md = 9 P, P = 2^lg = 2 .. 32 (8192 .. 131072 samples); ceil(md / 16)
+// tiles of 16 output columns; where the bucket bounds and the payload-order keys sit behind the list in buffer B (the
+// list holds at most two 12-byte points per admitted bin).
+struct FastGeo {
+    uint32_t md, lg, tiles;
+    bool ok;
+};
+// behind a list of the points of K bins (two 12-byte points each at most): the bucket bounds (3 x 256 words), then the
+// encoder's payload-order keys
+DEVI uint32_t fast_bounds_off(uint32_t K) { return (24u * K + 255u) & ~255u; }
+DEVI uint32_t fast_keys_off(uint32_t K) { return fast_bounds_off(K) + 4096u; }
+DEVI FastGeo fast_geo(const DevPlan &P)
+{
+    FastGeo g;
+    g.md = P.f4_m2;
+    const uint32_t p9 = P.f4_m2 / 9u;
+    g.ok = P.f4_m1 == FAST_MF && P.half && p9 * 9u == P.f4_m2 && p9 >= 2 && p9 <= 32 && (p9 & (p9 - 1)) == 0 && P.mf <= 1344;
+    g.lg = 31u - (uint32_t)__clz((int)(p9 | 1u));
+    g.tiles = (P.f4_m2 + 15u) / 16u;
+    return g;
+}
+// x mod (9 . 2^lg) for x < (9 . 2^lg)^2
+DEVI uint32_t fast_mod_md(uint32_t x, uint32_t lg)
+{
+    const uint32_t t = x >> lg, qq = (t * 7282u) >> 16;  // t < 81 . 2^lg <= 2592: t / 9 exactly
+    return ((t - 9u * qq) << lg) | (x & ((1u << lg) - 1u));
+}
 
 
 DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t n, uint32_t bitdepth, uint32_t K,
@@ -78,7 +106,7 @@ DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t 
 // harmonic on a multiple of L / 64 = 9 * 243.)
 template <class EntryFn>
 DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t M, SpEnt *zl, SpEnt *zs, uint32_t *tab,
-                          uint32_t *bcw, unsigned char *Bb)
+                          uint32_t *bcw, unsigned char *Bb, uint32_t bounds_off)
 {
     const uint32_t tid = threadIdx.x;
     uint32_t *beg = tab, *end = tab + 256, *cnt = tab + 512, *border = tab + 768;
@@ -88,22 +116,30 @@ DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t 
         uint32_t p;
         float2 x;
         if (!entry(i, p, x)) return 0;
-        // (p < M for this class: the first point always exists; it takes slot 0, the mirror slot 1)
-        {
+        // bin p <= M feeds point p of the packed spectrum (p < M: bin M = L / 2, which the shorter frames can admit,
+        // has no point of its own) and, as the conjugate partner, point M - p (p >= 1)
+        const bool has1 = p < M, has2 = p >= 1;
+        uint32_t k1 = 0, k2 = 0;
+        float2 v1 = make_float2(0.0f, 0.0f), v2 = v1;
+        if (has1) {
             const float2 h = make_float2(0.5f * x.x, 0.5f * x.y);
             const float2 o = cmulp(h, tw[p]);
-            kk[0] = p;
-            vv[0] = make_float2(h.x - o.y, -(h.y + o.x));
+            k1 = p;
+            v1 = make_float2(h.x - o.y, -(h.y + o.x));
         }
-        if (p >= 1) {
+        if (has2) {
             const float2 ee = make_float2(0.5f * x.x, -0.5f * x.y);
             const float2 d = make_float2(-0.5f * x.x, 0.5f * x.y);
             const float2 o = cmulp(d, tw[M - p]);
-            kk[1] = (M - p) | 0x80000000u;
-            vv[1] = make_float2(ee.x - o.y, -(ee.y + o.x));
-            return 2;
+            k2 = (M - p) | 0x80000000u;
+            v2 = make_float2(ee.x - o.y, -(ee.y + o.x));
         }
-        return 1;
+        // (slots by constant index: the arrays stay in registers)
+        kk[0] = has1 ? k1 : k2;
+        vv[0] = has1 ? v1 : v2;
+        kk[1] = k2;
+        vv[1] = v2;
+        return (has1 ? 1u : 0u) + (has2 ? 1u : 0u);
     };
     uint32_t mykk[2][2];
     float2 myvv[2][2];
@@ -180,7 +216,7 @@ DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t 
         uint32_t *gl = (uint32_t *)(Bb + FAST_LIST_OFF);
         const uint32_t *src = (const uint32_t *)zs;
         for (uint32_t w = tid; w < 3 * nlist; w += LT) gl[w] = src[w];
-        uint32_t *gb = (uint32_t *)(Bb + FAST_BOUNDS_OFF);
+        uint32_t *gb = (uint32_t *)(Bb + bounds_off);
         for (uint32_t e = tid; e < FAST_MF; e += LT) { gb[e] = beg[e]; gb[256 + e] = end[e]; gb[512 + e] = border[e]; }
     }
     return nlist;
@@ -209,9 +245,9 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
                (double)(stamp[2] - stamp[1]) * 0.01, (double)(stamp[3] - stamp[2]) * 0.01, (double)(stamp[4] - stamp[3]) * 0.01, \
                (double)(stamp[5] - stamp[4]) * 0.01, (double)(stamp[6] - stamp[5]) * 0.01, (double)(stamp[7] - stamp[6]) * 0.01); } while (0)
     FSTAMP(0);
-    if (P.f4_m1 != FAST_MF || P.f4_m2 != FAST_MD || !P.half || bins <= 65536 || bins - 65536 > FAST_OWN ||
-        P.mf > FAST_K_MAX)
-        return;
+    const FastGeo geo = fast_geo(P);
+    const bool wrap = bins > 65536;  // `pos as u16` (fft.rs:242) can fold two bins onto one stored position
+    if (!geo.ok || (wrap && bins - 65536 > FAST_OWN) || P.mf > FAST_K_MAX) return;
     // LDS: [wsum 80][bc 64][red 256][h2 2048 u32][own FAST_OWN u64][above FAST_K_MAX u64][cand FAST_CAND_MAX u64]
     uint32_t *wsum = (uint32_t *)smem;
     uint32_t *bc = (uint32_t *)(smem + 128);
@@ -469,7 +505,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     // ---- admission: sel[] (any order), sort keys for the payload, `pos as u16` owners, count of 3-byte positions ----
     Sel *sel = (Sel *)(ws + lay.o_sel);
     unsigned char *Bb = ws + lay.o_b;
-    unsigned long long *skey = (unsigned long long *)(Bb + FAST_KEYS_OFF);
+    unsigned long long *skey = (unsigned long long *)(Bb + fast_keys_off(K1));
     const float2 *spec = (const float2 *)(ws + lay.o_a);
     uint32_t big = 0;
     if (tid == 0) bc[2] = 0;
@@ -500,7 +536,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
             skey[i] = key;
             const uint32_t p16 = pos & 0xffffu;
             big += p16 >= 251 ? 1u : 0u;
-            if (p16 < FAST_OWN) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
+            if (wrap && p16 < FAST_OWN) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
         }
     }
     {
@@ -516,11 +552,11 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
             const Sel e = sel[i];
             p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
-            if (p < FAST_OWN && own[p] != skey[i]) return false;
+            if (wrap && p < FAST_OWN && own[p] != skey[i]) return false;
             x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
             return true;
         },
-        tw, M, (SpEnt *)cand, (SpEnt *)own, h2, bc + 10, Bb);  // (own[] is read by entry() before zs is first written)
+        tw, M, (SpEnt *)cand, (SpEnt *)own, h2, bc + 10, Bb, fast_bounds_off(K1));  // (own[] is read by entry() before zs is first written)
     FSTAMP(6);  // 6: bucketing
     if (tid == 0) {
         FastState f;
@@ -543,7 +579,10 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
 // Thread (column c, q): inputs ka = 9 a + q of its column straight from the buckets, then as k_large_cols243.
 // DECODE: the same tile for k_large_dparse's list, writing the frame's decoded samples (fft.rs:426-462) instead of an
 // error sum: FR = DevDFrame, io = the output buffer.
-template <bool DECODE, class FR>
+// LG: the frame's row dimension is md = 9 . 2^LG (LG = 5: 131072 samples); one instantiation per LG, launched when the
+// batch holds such frames -- the workgroups of a launch leave the frames of another LG alone.  (One kernel with md at run
+// time needs 170 VGPRs where the fixed form needs 161: two wavefronts per SIMD instead of three.)
+template <bool DECODE, class FR, int LG>
 __global__ __launch_bounds__(CT) void k_large_trip243(
     const double *__restrict__ samples, const FR *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base,
@@ -559,9 +598,10 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
     const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
     const FastState *fs = (const FastState *)(ws + lay.o_front);
+    if (fast_geo(P).lg != (uint32_t)LG) return;
     if constexpr (DECODE) {
         if (fs->status == 3) {
-            // A polynomial frame k_large_dparse prepared: this workgroup evaluates piece blockIdx.x of FAST_TILES
+            // A polynomial frame k_large_dparse prepared: this workgroup evaluates piece blockIdx.x of the frame's tiles
             // (polynomial.rs:342-373 with the encoder's tables -- tangents per segment, Hermite basis per in-segment
             // offset, exact r / step -- bit for bit the general decoder's values).
             const uint32_t n = P.n;
@@ -571,8 +611,10 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             double *out = frame_out(outp, fr);
             double4 *hbt = (double4 *)smem;                 // step <= 255 entries
             double2 *mms = (double2 *)(smem + 8192);        // segments of this piece
-            const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / FAST_TILES);
-            const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / FAST_TILES);
+            const uint32_t pieces = fast_geo(P).tiles;  // (the grid is as wide as the launch's widest frame)
+            if (blockIdx.x >= pieces) return;
+            const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / pieces);
+            const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / pieces);
             const uint32_t magic = (uint32_t)(0x100000000ull / step) + 1u;
             const uint32_t gapL = (n - 1) - (K - 2) * step;
             const double stepd = (double)step, gapLd = (double)gapL;
@@ -580,7 +622,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             uint32_t sgA = __umulhi(i0, magic), sgB = __umulhi(i1 - 1, magic);
             if (sgA > K - 2) sgA = K - 2;
             if (sgB > K - 2) sgB = K - 2;
-            if (sgB - sgA + 1 > 1536) return;  // (step >= 16: at most n / 18 / 16 + 2 segments)
+            if (sgB - sgA + 1 > 1536) return;  // (step >= 16 and pieces of at most 7282 samples: at most 457 segments)
             for (uint32_t sg = sgA + tid; sg <= sgB; sg += CT) {
                 double2 t = make_double2(0.0, 0.0);
                 if (sg >= 1 && sg + 2 < K) {
@@ -638,6 +680,9 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
         }
     }
     if (fs->status != 1) return;
+    const FastGeo geo = fast_geo(P);
+    if (blockIdx.x >= geo.tiles) return;  // (the grid is as wide as the launch's widest frame)
+    constexpr uint32_t lg = LG, MD = 9u << LG;
     const uint32_t n = P.n, L = P.L, pre = P.pre;
     const float2 *tw = twpool + P.tw_off;
     const double *xs = frame_samples(samples, fr);
@@ -650,13 +695,15 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     const SpEnt *gl = (const SpEnt *)(Bb + FAST_LIST_OFF);  // the list stays in memory (L2: the frame's 18 tiles share it)
     const uint32_t nlist = fs->nlist;
     {
-        const uint32_t *gb = (const uint32_t *)(Bb + FAST_BOUNDS_OFF);
+        const uint32_t *gb = (const uint32_t *)(Bb + fast_bounds_off(fs->K1));
         for (uint32_t e = tid; e < 256; e += CT) { beg[e] = gb[e]; end[e] = gb[256 + e]; border[e] = gb[512 + e]; }
         for (uint32_t e = tid; e < 243; e += CT) w1[e] = tw[e * (L / FAST_MF)];
-        for (uint32_t e = tid; e < FAST_MD; e += CT) wd[e] = tw[e * (L / FAST_MD)];
+        for (uint32_t e = tid; e < MD; e += CT) wd[e] = tw[e * (L / MD)];
     }
     const uint32_t c = tid & 15u, q = tid >> 4;
-    const uint32_t jb = blockIdx.x * 16 + c;
+    const uint32_t jb_raw = blockIdx.x * 16 + c;
+    const bool col_live = jb_raw < MD;           // (md = 18, 36, 72: the last tile is partly empty)
+    const uint32_t jb = col_live ? jb_raw : MD - 1;  // dead columns compute a live column's values and drop them
     const bool live = q < 9;
     __syncthreads();
     TSTAMP(1);
@@ -669,10 +716,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     // falls to (slots past the bucket's end add zeros).
     {
         const uint32_t grp = tid >> 4;  // 0 .. 11
-        auto mod288 = [](uint32_t x) -> uint32_t {  // x < 288 * 288
-            const uint32_t t = x >> 5, qq = (t * 7282u) >> 16;
-            return ((t - 9u * qq) << 5) | (x & 31u);
-        };
+
         auto fetch = [&](uint32_t e, uint32_t e1) -> SpEnt {
             SpEnt z;
             z.key = 0; z.re = 0.0f; z.im = 0.0f;
@@ -705,7 +749,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
                 const uint32_t ku = dpp_u32<0x150 + U, 0xf>(cur.key);                                             \
                 const float ru = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.re)));                \
                 const float iu = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.im)));                \
-                const float2 t = cmulc(make_float2(ru, iu), wd[mod288(jb * (ku >> 1))]);                          \
+                const float2 t = cmulc(make_float2(ru, iu), wd[fast_mod_md(jb * (ku >> 1), lg)]);                          \
                 acc.x += t.x;                                                                                     \
                 acc.y += t.y;                                                                                     \
             }
@@ -758,8 +802,8 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
 #pragma unroll
                 for (int kq = 0; kq < 9; ++kq) {  // idft_L = 2 idft_M: even sample -> re, odd sample -> -im
                     const uint32_t ja = ka + 27u * kq;
-                    const int32_t j2 = (int32_t)(2 * (FAST_MD * ja + jb)) - (int32_t)pre;  // even (pre and n are)
-                    if (j2 >= 0 && j2 < (int32_t)n) {
+                    const int32_t j2 = (int32_t)(2 * (MD * ja + jb)) - (int32_t)pre;  // even (pre and n are)
+                    if (col_live && j2 >= 0 && j2 < (int32_t)n) {
                         const double o0 = val(2.0f * b[kq].x), o1 = val(-2.0f * b[kq].y);
                         if (pair_ok) *(double2 *)(out + j2) = make_double2(o0, o1);
                         else { out[j2] = o0; out[j2 + 1] = o1; }
@@ -774,7 +818,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     // are even for this class: a pair never straddles a frame edge).  The samples of group m + 1 are requested while
     // group m is transformed and evaluated.
     double s = 0.0;
-    if (live) {
+    if (live && col_live) {
         const double mxd = (double)fs->mxf, mnd = (double)fs->mnf;
         const float Lf = (float)L;
         auto term = [&](float re, double gg) {  // fft.rs:341-345, utils/error.rs:104-116
@@ -788,7 +832,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
 #pragma unroll
             for (int kq = 0; kq < 9; ++kq) {
                 const uint32_t ja = (q + 9u * m) + 27u * kq;
-                const int32_t j2 = (int32_t)(2 * (FAST_MD * ja + jb)) - (int32_t)pre;
+                const int32_t j2 = (int32_t)(2 * (MD * ja + jb)) - (int32_t)pre;
                 const int32_t jc = j2 < 0 ? 0 : (j2 >= (int32_t)n ? (int32_t)n - 2 : j2);
                 double2 v = *(const double2 *)(xs + jc);
                 if (j2 < 0) v.y = v.x;
@@ -857,7 +901,8 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     if (tid == 0) {  // the tiles' sums, in tile order
         double s = 0.0;
         const double *part = (const double *)(ws + lay.o_c + FAST_PARTIAL_OFF);
-        for (uint32_t t = 0; t < FAST_TILES; ++t) s += part[t];
+        const uint32_t tiles = fast_geo(P).tiles;
+        for (uint32_t t = 0; t < tiles; ++t) s += part[t];
         *(double *)(smem + 256) = s;
     }
     __syncthreads();
@@ -932,9 +977,8 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     const LargeWs lay = large_ws_layout(fr.n, L, P.kcap);
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
-    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL) || P.f4_m1 != FAST_MF || P.f4_m2 != FAST_MD || !P.half ||
-        (P.pre & 1u) || (fr.n & 1u))
-        return;
+    const FastGeo geo = fast_geo(P);
+    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL) || !geo.ok || (P.pre & 1u) || (fr.n & 1u)) return;
     // LDS: [hdr 512][payload window STG_BYTES][tab 1024 u32][pos FAST_K_MAX u32 + dead FAST_K_MAX u32][zl][zs]
     uint32_t *bc = (uint32_t *)smem;
     float *bcf = (float *)(smem + 64);
@@ -1064,7 +1108,7 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
         (void)rds_u8(r);
         const uint64_t cnt64 = rds_varint(r);
         if (tid == 0) {
-            bc[0] = (!r.bad && cnt64 >= 1 && cnt64 <= FAST_K_MAX && r.pos + 8 <= r.len) ? 1u : 0u;
+            bc[0] = (!r.bad && cnt64 >= 1 && cnt64 <= FAST_K_MAX && cnt64 <= P.kcap && r.pos + 8 <= r.len) ? 1u : 0u;
             bc[1] = (uint32_t)cnt64;
             bc[2] = r.pos;
             bc[3] = 0;  // raised by a group that does not parse
@@ -1153,11 +1197,11 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
             if (ldead[i]) return false;
             const Sel e = ent[i];
             p = e.pos;
-            if (p >= M) return false;  // (cannot be: positions are u16, M = 69984)
+            if (p > M) return false;  // (cannot be: the entries come mirrored into [0, L / 2])
             x = make_float2(e.re, e.im);
             return true;
         },
-        tw, M, zl, zs, tab, bc + 8, ws + lay.o_b);
+        tw, M, zl, zs, tab, bc + 8, ws + lay.o_b, fast_bounds_off(cnt));
     if (tid == 0) {
         fs->nlist = nlist;
         fs->mxf = mxf;

@@ -453,6 +453,8 @@ def test_unbounded_fft(ctx, A, oracle):
 @pytest.mark.parametrize("sizes,klasses", [
     ([8192, 5000, 6500, 16384, 4097], (0, 2, 3, 1)),   # 6500 -> L = 6561 = 3^8 (odd: full complex FFT)
     ([32768, 65536], (0, 3)),
+    # every power-of-two chunk from 8192 samples up has M = 243 x 9 P: the grid path of atsc_large_fast.h, all classes
+    ([8192, 16384, 32768, 65536], (0, 1, 2, 3, 4)),
     ([131072], (0,)),
     ([131072], (1,)),                                    # busy signal: bins >= 65536 are admitted (u16 wrap)
 ])
@@ -503,6 +505,36 @@ def test_decompress_large_frames(ctx, A, oracle):
                 n = int(off[i + 1] - off[i])
                 scale = max(np.max(np.abs(ref[seg])), 1e-30)
                 tol = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5  # f32 FFT of length ~n
+                assert np.max(np.abs(out[seg] - ref[seg])) <= tol, (comp, i, np.max(np.abs(out[seg] - ref[seg])), tol)
+            else:
+                assert np.array_equal(out[seg], ref[seg]), (comp, i, chosen[i])
+
+
+@pytest.mark.parametrize("me", [ME5, ME1])
+def test_decompress_power_of_two_large_frames(ctx, A, oracle, me):
+    """The ORACLE's stream of 8192 ... 131072-sample frames (all of them M = 243 x 9 P: k_large_dparse +
+    k_large_trip243<true> per row dimension) decoded on the GPU against the oracle's decode."""
+    sizes = [8192, 16384, 32768, 65536, 131072]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in ((0, 1, 2, 3, 4) if n < 100000 else (0, 2)):
+            xs.append(H.synth_series(900 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    nf = len(off) - 1
+    for comp in (A.AUTO, A.FFT, A.POLYNOMIAL):
+        bro, chosen, _ = oracle.stream_compress(x, off, comp, True, me, 0)
+        ref = oracle.decompress_data(bro)
+        body_off, nfr = A.bro_open(bro)
+        out = ctx.decompress_host(bro[body_off:])
+        assert len(out) == len(ref)
+        for i in range(nf):
+            seg = slice(int(off[i]), int(off[i + 1]))
+            if chosen[i] == oracle.FFT:
+                n = int(off[i + 1] - off[i])
+                scale = max(np.max(np.abs(ref[seg])), 1e-30)
+                tol = (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5
                 assert np.max(np.abs(out[seg] - ref[seg])) <= tol, (comp, i, np.max(np.abs(out[seg] - ref[seg])), tol)
             else:
                 assert np.array_equal(out[seg], ref[seg]), (comp, i, chosen[i])
@@ -1133,10 +1165,13 @@ def test_large_fast_path_matches_general_kernel(ctx, A, oracle, monkeypatch):
     butterfly orders: the coefficients agree to f32 accuracy, so the two forms must choose the same codecs with
     the same K, report the same error to the decode bar's accuracy, and both decoders must reproduce the oracle's
     decode of either stream (polynomial / RLE / constant frames bit for bit)."""
-    F = 131072
-    xs = [H.synth_series(1500 + c, 2 * F, klass=c) for c in (0, 1, 2, 3, 4)]
+    xs, offs = [], [0]
+    for F in (131072, 131072, 65536, 32768, 16384, 8192):
+        for c in (0, 1, 2, 3, 4):
+            xs.append(H.synth_series(1500 + c + F % 97, F, klass=c))
+            offs.append(offs[-1] + F)
     x = np.concatenate(xs)
-    off = H.frame_offsets(len(x), F)
+    off = np.array(offs, dtype=np.uint64)
     nf = len(off) - 1
     for me in (ME5, ME1):
         monkeypatch.delenv("ATSC_LARGE_NO_FAST", raising=False)
@@ -1158,7 +1193,7 @@ def test_large_fast_path_matches_general_kernel(ctx, A, oracle, monkeypatch):
                 tol = P.FFT_ERR_ATOL + P.FFT_ERR_RTOL * abs(err_g[i]) + P.fft_err_noise(x[seg])
                 assert abs(err_f[i] - err_g[i]) <= tol, (me, i, err_f[i], err_g[i])
                 scale = max(np.max(np.abs(ref[seg])), 1e-30)
-                t = (4 + np.log2(F)) * scale * 2.0 ** -23 + 1.00001e-5
+                t = (4 + np.log2(seg.stop - seg.start)) * scale * 2.0 ** -23 + 1.00001e-5
                 assert np.max(np.abs(out_ff[seg] - ref[seg])) <= t and np.max(np.abs(out_fg[seg] - ref[seg])) <= t, (me, i)
             else:
                 assert ff[i] == fg[i], (me, i)

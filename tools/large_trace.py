@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, atsc_amd
 from tests import helpers as H
-F = 131072; nf = int(os.environ.get("NF", "80")); n = nf * F
+F = int(os.environ.get("FLEN", "131072")); nf = int(os.environ.get("NF", "80")); n = nf * F
 me = float(np.float32(5) / np.float32(100))
 dev = torch.device("cuda:0")
 ctx = atsc_amd.Context(0)
