@@ -62,7 +62,8 @@ static const uint32_t LARGE_WS_SLOTS = 256;      // large frames in flight (one 
 // 8192-sample frames is 2 M samples: every grid of the large tier would be latency-bound on it)
 static uint32_t large_ws_slots(uint64_t ws_stride)
 {
-    const uint64_t budget = 800ull << 20;
+    uint64_t budget = 1600ull << 20;
+    if (const char *e = getenv("ATSC_LARGE_WS_MB")) budget = (uint64_t)std::max(1, atoi(e)) << 20;
     const uint64_t fit = ws_stride ? budget / ws_stride : LARGE_WS_SLOTS;
     return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(LARGE_WS_SLOTS, fit));
 }

@@ -427,20 +427,6 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
     const uint32_t M1 = f.M1, M = f.M;
     if (f.M2 != M2) return;
     const uint32_t half_pairs = (M1 - 1) / 2;
-    uint32_t a0 = 0, cnt = 0, nrow;
-    if (blockIdx.x == 0) {
-        nrow = (M1 % 2 == 0 && M1 >= 2) ? 2u : 1u;
-    } else {
-        const uint32_t first = (blockIdx.x - 1) * FBH;
-        if (first >= half_pairs) return;
-        a0 = 1 + first;
-        cnt = min(FBH, half_pairs - first);
-        nrow = 2 * cnt;
-    }
-    auto row_of = [&](uint32_t r) -> uint32_t {
-        if (blockIdx.x == 0) return r == 0 ? 0u : M1 / 2;
-        return r < cnt ? a0 + r : M1 - a0 - cnt + 1 + (r - cnt);
-    };
     const LargeWs lay = large_ws_layout(f.n, f.L, Pl->kcap);
     const float2 *Y = (const float2 *)(f.ws + lay.o_b);
     float2 *spec = (float2 *)(f.ws + lay.o_a);
@@ -449,93 +435,126 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
     const float2 *tw = twpool + Pl->tw_off;
     const uint32_t tid = threadIdx.x;
     for (uint32_t e = tid; e < M2; e += RT) w2[e] = tw[e * (M1 * f.sc)];
-    // ---- step 1 ----
-    constexpr int IT1 = (FB * P + RT - 1) / RT;  // items per thread
-    float2 b[IT1][9];
-#pragma unroll
-    for (int s = 0; s < IT1; ++s) {
-        const uint32_t it = tid + s * RT, r = it / P, v = it % P;
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            b[s][u] = make_float2(0.0f, 0.0f);
-            if (it < FB * P && r < nrow) b[s][u] = Y[row_of(r) * M2 + P * u + v];
-        }
-    }
+    // Short rows (P <= 8): a workgroup takes G tiles one after the other -- a tile of 16 rows is 288 points at P = 2, and a
+    // workgroup per tile spends its life on the launch, the table and three barriers (the other workgroups of such a
+    // group leave at once)
+    constexpr uint32_t G = (P <= 4) ? 4u : (P == 8 ? 2u : 1u);
+    if (blockIdx.x % G) return;
+    uint32_t zeros = 0;
     __syncthreads();  // w2
-#pragma unroll
-    for (int s = 0; s < IT1; ++s) {
-        const uint32_t it = tid + s * RT, r = it / P, v = it % P;
-        if (it < FB * P && r < nrow) {
-            dft9f(b[s]);
-#pragma unroll
-            for (int ku = 0; ku < 9; ++ku) {
-                const float2 z = ku ? cmulc(b[s][ku], w2[v * ku]) : b[s][0];
-                T[(r * 9 + ku) * BS + v] = z;
+    auto do_tile = [&](const uint32_t bx) -> bool {
+        uint32_t a0 = 0, cnt = 0, nrow;
+        if (bx == 0) {
+            nrow = (M1 % 2 == 0 && M1 >= 2) ? 2u : 1u;
+        } else {
+            const uint32_t first = (bx - 1) * FBH;
+            if (first >= half_pairs) return false;
+            a0 = 1 + first;
+            cnt = min(FBH, half_pairs - first);
+            nrow = 2 * cnt;
+        }
+        auto row_of = [&](uint32_t r) -> uint32_t {
+            if (bx == 0) return r == 0 ? 0u : M1 / 2;
+            return r < cnt ? a0 + r : M1 - a0 - cnt + 1 + (r - cnt);
+        };
+        // ---- step 1 ----
+        constexpr int IT1 = (FB * P + RT - 1) / RT;  // items per thread
+        float2 b[IT1][9];
+    #pragma unroll
+        for (int s = 0; s < IT1; ++s) {
+            const uint32_t it = tid + s * RT, r = it / P, v = it % P;
+    #pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                b[s][u] = make_float2(0.0f, 0.0f);
+                if (it < FB * P && r < nrow) b[s][u] = Y[row_of(r) * M2 + P * u + v];
             }
         }
-    }
-    __syncthreads();
-    // ---- step 2: item (r, ku), r = tid & 15 ----
-    const uint32_t r = tid & (FB - 1), ku2 = tid >> 4;
-    const bool live = r < nrow;
-    {
-        float2 c[P];
-        const bool act = live && ku2 < 9;
-        if (act) {
-#pragma unroll
-            for (int v = 0; v < P; ++v) c[v] = T[(r * 9 + ku2) * BS + v];
-            dft_pow2f<P>(c);
+        __syncthreads();  // w2
+    #pragma unroll
+        for (int s = 0; s < IT1; ++s) {
+            const uint32_t it = tid + s * RT, r = it / P, v = it % P;
+            if (it < FB * P && r < nrow) {
+                dft9f(b[s]);
+    #pragma unroll
+                for (int ku = 0; ku < 9; ++ku) {
+                    const float2 z = ku ? cmulc(b[s][ku], w2[v * ku]) : b[s][0];
+                    T[(r * 9 + ku) * BS + v] = z;
+                }
+            }
         }
         __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int kv = 0; kv < P; ++kv) T[r * ZS + ku2 + 9 * kv] = c[kv];
+        // ---- step 2: item (r, ku), r = tid & 15 ----
+        const uint32_t r = tid & (FB - 1), ku2 = tid >> 4;
+        const bool live = r < nrow;
+        {
+            float2 c[P];
+            const bool act = live && ku2 < 9;
+            if (act) {
+    #pragma unroll
+                for (int v = 0; v < P; ++v) c[v] = T[(r * 9 + ku2) * BS + v];
+                dft_pow2f<P>(c);
+            }
+            __syncthreads();
+            if (act) {
+    #pragma unroll
+                for (int kv = 0; kv < P; ++kv) T[r * ZS + ku2 + 9 * kv] = c[kv];
+            }
         }
-    }
-    // twiddles of this thread's bins (issued before the barrier: a dependent global load per bin otherwise)
-    constexpr uint32_t PU2 = (M2 + (RT / FB) - 1) / (RT / FB);
-    const uint32_t kc0 = tid >> 4;
-    const uint32_t k1 = live ? row_of(r) : 0u;
-    float2 twk[PU2];
-#pragma unroll
-    for (uint32_t u = 0; u < PU2; ++u) {
-        const uint32_t k2 = kc0 + u * (RT / FB);
-        twk[u] = make_float2(1.0f, 0.0f);
-        if (live && k2 < M2 && f.half) twk[u] = tw[k1 + M1 * k2];
-    }
-    __syncthreads();
-    // ---- step 3 ----
-    const bool dense = !(sparse_inv && Pl->sp_mf);
-    uint32_t zeros = 0;
-    auto finish = [&](uint32_t k, float2 z) {
-        spec[k] = z;
-        nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
-        zeros += (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
-        if (dense) Xs[k] = make_float2(0.0f, 0.0f);
-    };
-    const bool row0 = blockIdx.x == 0 && r == 0;
-    const float2 *Rrow = T + r * ZS;
-    const float2 *Rpart = T + ((blockIdx.x == 0) ? r : (nrow - 1 - r)) * ZS;
-    auto untangle = [&](float2 zk, float2 zm, float2 wk) -> float2 {  // see fft_untangle (atsc_kernels.hip)
-        const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
-        const float2 bb = make_float2(zk.x - zm.x, zk.y + zm.y);
-        const float2 t = cmulc(make_float2(bb.y, -bb.x), wk);
-        return make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
-    };
-#pragma unroll
-    for (uint32_t u = 0; u < PU2; ++u) {
-        const uint32_t k2 = kc0 + u * (RT / FB);
-        if (!live || k2 >= M2) continue;
-        const uint32_t k = k1 + M1 * k2;
-        const float2 zk = Rrow[k2];
-        if (!f.half) {
-            if (k < f.bins) finish(k, zk);
-            else spec[k] = zk;
-            continue;
+        // twiddles of this thread's bins (issued before the barrier: a dependent global load per bin otherwise)
+        constexpr uint32_t PU2 = (M2 + (RT / FB) - 1) / (RT / FB);
+        const uint32_t kc0 = tid >> 4;
+        const uint32_t k1 = live ? row_of(r) : 0u;
+        float2 twk[PU2];
+    #pragma unroll
+        for (uint32_t u = 0; u < PU2; ++u) {
+            const uint32_t k2 = kc0 + u * (RT / FB);
+            twk[u] = make_float2(1.0f, 0.0f);
+            if (live && k2 < M2 && f.half) twk[u] = tw[k1 + M1 * k2];
         }
-        const float2 zm = Rpart[row0 ? (k2 == 0 ? 0u : M2 - k2) : (M2 - 1 - k2)];
-        finish(k, untangle(zk, zm, twk[u]));
-        if (k == 0) finish(M, untangle(zk, zk, tw[M]));
+        __syncthreads();
+        // ---- step 3 ----
+        const bool dense = !(sparse_inv && Pl->sp_mf);
+        auto finish = [&](uint32_t k, float2 z) {
+            spec[k] = z;
+            nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
+            zeros += (z.x != 0.0f || z.y != 0.0f) ? 0u : 1u;
+            if (dense) Xs[k] = make_float2(0.0f, 0.0f);
+        };
+        const bool row0 = bx == 0 && r == 0;
+        const float2 *Rrow = T + r * ZS;
+        const float2 *Rpart = T + ((bx == 0) ? r : (nrow - 1 - r)) * ZS;
+        auto untangle = [&](float2 zk, float2 zm, float2 wk) -> float2 {  // see fft_untangle (atsc_kernels.hip)
+            const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 bb = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 t = cmulc(make_float2(bb.y, -bb.x), wk);
+            return make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+        };
+    #pragma unroll
+        for (uint32_t u = 0; u < PU2; ++u) {
+            const uint32_t k2 = kc0 + u * (RT / FB);
+            if (!live || k2 >= M2) continue;
+            const uint32_t k = k1 + M1 * k2;
+            const float2 zk = Rrow[k2];
+            if (!f.half) {
+                if (k < f.bins) finish(k, zk);
+                else spec[k] = zk;
+                continue;
+            }
+            const float2 zm = Rpart[row0 ? (k2 == 0 ? 0u : M2 - k2) : (M2 - 1 - k2)];
+            finish(k, untangle(zk, zm, twk[u]));
+            if (k == 0) finish(M, untangle(zk, zk, tw[M]));
+        }
+        return true;
+    };
+    if constexpr (G == 1) {
+        (void)do_tile(blockIdx.x);
+    } else {
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t bx = blockIdx.x + g;
+            if (bx >= row_tiles) break;
+            if (g) __syncthreads();  // the tile buffer is free again
+            if (!do_tile(bx)) break;
+        }
     }
     if (__ballot(zeros != 0)) {
         zeros = wave_sum_u32(zeros);

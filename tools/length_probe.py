@@ -13,7 +13,7 @@ ctx = atsc_amd.Context(0)
 st = torch.cuda.current_stream().cuda_stream
 x = H.synth_series(0, N)
 d_x = torch.from_numpy(x).to(dev)
-for F in (64, 128, 256, 300, 512, 1024, 2048, 4096, 8192, 32768):
+for F in (64, 128, 256, 300, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
     off = H.frame_offsets(N, F)
     plan = ctx.plan(off)
     outs = plan.alloc_outputs(torch, dev)
