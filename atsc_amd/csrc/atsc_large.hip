@@ -2552,8 +2552,9 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                 launch_rows9p(pre->rows9p, tiles23, 0, nb, s, samples, frames, ids + b0, plans, twpool, ws, ws_stride,
                               (int)kp.sparse_inv);
             }
-            hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), FAST_D1_LDS, s, samples, frames, ids + b0, plans,
-                               twpool, kp, slots, res, ws, ws_stride);
+            const FastCarve cv = fast_carve(pre->m2_max);
+            hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), fast_d1_lds(cv), s, samples, frames, ids + b0, plans,
+                               twpool, kp, slots, res, ws, ws_stride, cv);
             e = launch_trip243<false, DevFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, samples, frames, ids + b0, plans, twpool,
                                                 ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
             if (e != hipSuccess) return e;

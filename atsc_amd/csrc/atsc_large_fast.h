@@ -57,6 +57,25 @@ DEVI uint32_t fast_mod_md(uint32_t x, uint32_t lg)
 }
 
 
+// k_large_decide1's LDS carve-up, chosen per launch from its longest frame: the arrays a 131072-sample frame needs
+// (owner table of the u16 wrap, 1344 keys, 6144 candidates: 124 KB, one workgroup per CU) would leave a launch of
+// 8192-sample frames -- 81 bins to admit each -- at one frame per CU.  own[] and cand[] also host the two list buffers
+// of the bucket builder (two 12-byte points per bin: 3 mf u64 each).
+struct FastCarve {
+    uint32_t own_n, k_max, cand_max;  // u64 entries
+};
+inline FastCarve fast_carve(uint32_t m2_max)
+{
+    FastCarve c;
+    if (m2_max >= FAST_MD) { c.own_n = FAST_OWN; c.k_max = FAST_K_MAX; c.cand_max = FAST_CAND_MAX; return c; }
+    const uint32_t mf_bound = 5u * m2_max;  // mf = n / 100 < 2 . 243 . m2 / 100
+    c.k_max = (mf_bound + 63u) & ~63u;
+    c.own_n = (3u * mf_bound + 63u) & ~63u;
+    c.cand_max = c.own_n > 4096u ? c.own_n : 4096u;  // (2048: a fifth of the 8192-sample frames of the mixed workload overflow it)
+    return c;
+}
+inline uint32_t fast_d1_lds(const FastCarve &c) { return 512 + 16384 + 8 * (c.own_n + 2 * c.k_max + c.cand_max); }
+
 DEVI void fast_emit_poly(uint8_t *out, DevResult &r, const double *xs, uint32_t n, uint32_t bitdepth, uint32_t K,
                          uint32_t step, double smin, double smax, double err, uint32_t *aux, uint32_t *wsum)
 {
@@ -222,10 +241,11 @@ DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t 
     return nlist;
 }
 
-__global__ __launch_bounds__(LT) void k_large_decide1(
+__global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_large_decide1(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
-    uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride)
+    uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+    const FastCarve cv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
@@ -247,17 +267,18 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     FSTAMP(0);
     const FastGeo geo = fast_geo(P);
     const bool wrap = bins > 65536;  // `pos as u16` (fft.rs:242) can fold two bins onto one stored position
-    if (!geo.ok || (wrap && bins - 65536 > FAST_OWN) || P.mf > FAST_K_MAX) return;
-    // LDS: [wsum 80][bc 64][red 256][h2 2048 u32][own FAST_OWN u64][above FAST_K_MAX u64][cand FAST_CAND_MAX u64]
+    if (!geo.ok || (wrap && bins - 65536 > cv.own_n) || P.mf > cv.k_max || 3 * P.mf > cv.own_n || 3 * P.mf > cv.cand_max) return;
+    // LDS: [wsum 80][bc 64][red 256][h2 2048 u32][dcnt 2048 u32][own cv.own_n u64][above cv.k_max u64][sorted cv.k_max u64]
+    // [cand cv.cand_max u64]  (the launch's carve-up, fast_carve: sized for its longest frame)
     uint32_t *wsum = (uint32_t *)smem;
     uint32_t *bc = (uint32_t *)(smem + 128);
     double *bcd = (double *)(smem + 192);
     uint32_t *h2 = (uint32_t *)(smem + 512);
     uint32_t *dcnt = (uint32_t *)(smem + 512 + 8192);  // 2048 per-digit cursors
     unsigned long long *own = (unsigned long long *)(smem + 512 + 16384);
-    unsigned long long *above = own + FAST_OWN;
-    unsigned long long *sorted = above + FAST_K_MAX;
-    unsigned long long *cand = sorted + FAST_K_MAX;
+    unsigned long long *above = own + cv.own_n;
+    unsigned long long *sorted = above + cv.k_max;
+    unsigned long long *cand = sorted + cv.k_max;
     const double *xs = samples + fr.sample_off;
     const float2 *tw = twpool + P.tw_off;
     uint8_t *out = slots + fr.slot_off;
@@ -375,7 +396,8 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     // ---- the K1 largest norms (fft.rs:231-257), as a set ----
     const uint32_t *nbits = (const uint32_t *)(ws + lay.o_nb);
     for (uint32_t i = tid; i < 2048; i += LT) { h2[i] = 0; dcnt[i] = 0; }
-    for (uint32_t i = tid; i < FAST_OWN; i += LT) own[i] = 0ull;
+    if (wrap)
+        for (uint32_t i = tid; i < cv.own_n; i += LT) own[i] = 0ull;
     if (tid < 16) bc[tid] = 0;
     if (tid == 0) bc[4] = 0xFFFFFFFFu;
     __syncthreads();
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
     }
     if (bc[4] == 0xFFFFFFFFu) return;
     const uint32_t dstar = 2047u - bc[4], n_above = bc[5], n_cand = bc[6];
-    if (n_cand > FAST_CAND_MAX) return;
+    if (n_cand > cv.cand_max) return;
     {
         const uint32_t lane = tid & 63u;
         const uint64_t lt = (1ull << lane) - 1ull;
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
             skey[i] = key;
             const uint32_t p16 = pos & 0xffffu;
             big += p16 >= 251 ? 1u : 0u;
-            if (wrap && p16 < FAST_OWN) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
+            if (wrap && p16 < cv.own_n) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
         }
     }
     {
@@ -552,7 +574,7 @@ __global__ __launch_bounds__(LT) void k_large_decide1(
         [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
             const Sel e = sel[i];
             p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
-            if (wrap && p < FAST_OWN && own[p] != skey[i]) return false;
+            if (wrap && p < cv.own_n && own[p] != skey[i]) return false;
             x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
             return true;
         },
