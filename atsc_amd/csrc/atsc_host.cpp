@@ -1888,12 +1888,21 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
     if (!ctx || !body || !out) return fail(ctx, ATSC_E_INVALID, "dplan_create: null argument");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    static const bool trace = getenv("ATSC_TRACE_HOST") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dplan]      %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     DPlanHost H;
     {
         const char *why;
         int rc = dplan_parse(body, body_len, has_count, H, &why);
         if (rc) return fail(ctx, rc, why);
     }
+    lap("record walk");
     atsc_dplan *p = new (std::nothrow) atsc_dplan();
     if (!p) return ATSC_E_NOMEM;
     p->ctx = ctx;
@@ -1927,8 +1936,10 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
             if (p->tabs.plans[pi].sp_mf) p->large_sp_tiles = std::max(p->large_sp_tiles, (p->tabs.plans[pi].sp_md + 7) / 8);
         if (getenv("ATSC_LARGE_DECODE_ONE_KERNEL")) p->large_sp_tiles = 0;
     }
+    lap("class lists");
     int rc = upload_tables(ctx, p->tabs);
     if (rc) { atsc_dplan_destroy(p); return rc; }
+    lap("tables up");
 #define PCHK(call)                                                                      \
     do {                                                                                \
         hipError_t e__ = (call);                                                        \
@@ -1945,6 +1956,7 @@ extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t bo
         PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
     }
 #undef PCHK
+    lap("frames + ids up");
     *out = p;
     return ATSC_OK;
     ATSC_API_END
