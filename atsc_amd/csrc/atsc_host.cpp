@@ -575,6 +575,11 @@ extern "C" int atsc_ctx_create(atsc_ctx **out, int device)
     if (const char *ds = getenv("ATSC_DEBUG_STOP")) c->debug_stop = atoi(ds);
     if (getenv("ATSC_NO_ADAPTIVE_ORDER")) c->adaptive_order = false;
     if (getenv("ATSC_ADAPTIVE_ORDER")) c->adaptive_order = true;
+    // Two chains by default; four where the process runs with eight or more hardware queues (GPU_MAX_HW_QUEUES, read by
+    // the HIP runtime at start-up: four by default): with four queues, four chains plus the caller's stream share
+    // queues and gain nothing over two (106 us per step either way), with eight they are worth 3 % (97 -> 100 Gsamples/s,
+    // three runs each)
+    if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) c->n_chains = atoi(hq) >= 8 ? 4 : 2;
     if (const char *ch = getenv("ATSC_CHAINS")) c->n_chains = std::min(4, std::max(1, atoi(ch)));
     *out = c;
     return ATSC_OK;

@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="plain single-stream calls (atsc_compress_plan_dev) instead of the chained entry point "
                          "(atsc_compress_plan_dev_pipelined)")
-    ap.add_argument("--chains", type=int, default=0, help="chains of the pipelined entry point (1..4; 0: the library's default, 2)")
+    ap.add_argument("--chains", type=int, default=0, help="chains of the pipelined entry point (1..4; 0: the library's default: 4 with GPU_MAX_HW_QUEUES >= 8, which this script sets, else 2)")
     ap.add_argument("--no-decompress", action="store_true", help="skip the decompression measurement")
     ap.add_argument("--no-adaptive-order", action="store_true", help="configs[3] workload: frames in index order (see --adaptive-order)")
     ap.add_argument("--adaptive-order", action="store_true",
@@ -582,7 +582,7 @@ def main():
             km, kl = ctx.profile_read()
             ctx.set_profiling(False)
             ctx.set_adaptive_order(bool(args.adaptive_order))
-            ctx.set_chains(args.chains if args.chains else 2)
+            ctx.set_chains(args.chains if args.chains else (4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else 2))
             ordered = {"kernel_ms_avg": km / max(kl, 1), "launches": kl, "ms_per_step": dt_o / args.steps * 1e3,
                        "note": "one chain, cost order from the SAME resident batch (exact hint), as rounds 1-2 measured it"}
 
@@ -679,7 +679,7 @@ def main():
                 "gathered_bytes_last_step": gathered_sizes,
                 "pipeline": ("atsc_compress_plan_dev_pipelined: consecutive batches rotate over %s chains (streams of the "
                              "context's own, two scratch sets each); frames start in %s"
-                             % (args.chains or "the default 2",
+                             % (args.chains or "the default %d" % (4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else 2),
                                 "index order (no cost hint)" if not args.adaptive_order else
                                 ("cost order (clocks of the same slot in an earlier batch of the chain -- another resident "
                                  "batch: other values of the same series, same class)" if workload == "config3" else

@@ -151,8 +151,9 @@ int atsc_compress_plan_dev_pipelined(atsc_ctx *ctx, const atsc_plan *plan, const
                                      int sample_level, uint8_t *d_body, uint64_t body_cap,
                                      uint64_t *d_rec_off, uint8_t *d_chosen, double *d_err,
                                      void *stream);
-/* Chains the pipelined calls of this context rotate over (1..4, default 4; ATSC_CHAINS overrides the
- * default).  1 keeps every batch on one stream of the context's. */
+/* Chains the pipelined calls of this context rotate over (1..4; default 2, or 4 in a process started with
+ * GPU_MAX_HW_QUEUES >= 8 -- four chains plus the caller's streams need more hardware queues than the runtime's default
+ * four to pay; ATSC_CHAINS overrides the default).  1 keeps every batch on one stream of the context's. */
 int atsc_ctx_set_chains(atsc_ctx *ctx, int n);
 /* Pipelined calls record how many shader clocks every frame took and start the next batches of the
  * same plan with a class's costliest frames first (frame i of a recurring batch is the same series,
