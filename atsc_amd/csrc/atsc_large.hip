@@ -2471,8 +2471,19 @@ static void launch_rows9p(uint32_t pmask, uint32_t row_tiles, uint32_t pieces, u
     if (pmask & 32u) hipLaunchKernelGGL(k_large_rows9p<32>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
     if (pmask & 16u) hipLaunchKernelGGL(k_large_rows9p<16>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
     if (pmask & 8u) hipLaunchKernelGGL(k_large_rows9p<8>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
-    if (pmask & 4u) hipLaunchKernelGGL(k_large_rows9p<4>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
-    if (pmask & 2u) hipLaunchKernelGGL(k_large_rows9p<2>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+    // rows of 18 points: one thread per row, one workgroup per frame (k_large_rows_thread)
+    static const bool old_rows = getenv("ATSC_LARGE_ROWS9P_ONLY") != nullptr;
+    const dim3 gt(1 + pieces, nb);
+    // (36-point rows: 166 VGPRs and 70 KB of LDS leave two such workgroups on a CU: 16384-sample frames 46 -> 42 Gsamples/s)
+    static const bool thread4 = getenv("ATSC_LARGE_ROWS_THREAD4") != nullptr;
+    if (pmask & 4u) {
+        if (!thread4) hipLaunchKernelGGL(k_large_rows9p<4>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+        else hipLaunchKernelGGL(k_large_rows_thread<4>, gt, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv);
+    }
+    if (pmask & 2u) {
+        if (old_rows) hipLaunchKernelGGL(k_large_rows9p<2>, g, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv, row_tiles);
+        else hipLaunchKernelGGL(k_large_rows_thread<2>, gt, dim3(RT), 0, s, samples, frames, ids, plans, twpool, ws, ws_stride, sparse_inv);
+    }
 }
 
 hipError_t launch_compress_large(uint32_t count, const double *samples, const DevFrame *frames,

@@ -561,3 +561,101 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
         if ((tid & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
     }
 }
+
+// The same row pass for the two shortest row dimensions (M2 = 18, 36: frames of 8192 and 16384 samples), one THREAD per
+// row: a frame's 243 rows fit one workgroup, a row's 9 P points fit a thread's registers, and what k_large_rows9p<P> does
+// through three barriers and two trips through LDS per 16-row tile -- with most of its 256 threads idle on rows this
+// short -- is a straight run here: load the row, radix 9 over u, twiddle, radix P over v (the same butterflies and the
+// same twiddles, operation for operation), one exchange through LDS for the untangle step's partner row (thread r
+// needs row M1 - r mirrored), stores with consecutive threads on consecutive bins.  1280 frames of 8192 samples:
+// 93 -> ~15 us.  Workgroups behind the first (blockIdx.x >= 1) are the first polynomial trip's pieces, as in
+// k_large_rows9p.
+template <int P>
+__global__ __launch_bounds__(RT) void k_large_rows_thread(const double *__restrict__ samples,
+                                                           const DevFrame *__restrict__ frames,
+                                                           const uint32_t *__restrict__ ids,
+                                                           const DevPlan *__restrict__ plans,
+                                                           const float2 *__restrict__ twpool,
+                                                           unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+                                                           int sparse_inv)
+{
+    constexpr uint32_t M2 = 9 * P, TS = 244;  // TS: row stride of the exchange buffer (one column of all rows, padded)
+    constexpr uint32_t NPT0 = M2 * TS;
+    constexpr uint32_t NPT = NPT0 > 2112 ? NPT0 : 2112;  // (the polynomial pieces borrow the buffer: 16.5 KB)
+    __shared__ float2 w2[M2];
+    __shared__ __attribute__((aligned(16))) float2 T[NPT];
+    const DevPlan *Pl;
+    const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, Pl);
+    if (f.M2 != M2 || f.M1 != 243 || !f.half) return;
+    const LargeWs lay = large_ws_layout(f.n, f.L, Pl->kcap);
+    if (blockIdx.x >= 1) {
+        poly1_piece(f.xs, *Pl, f.ws, lay, blockIdx.x - 1, (unsigned char *)T);
+        return;
+    }
+    constexpr uint32_t M1 = 243;
+    const uint32_t M = f.M;
+    const float2 *Y = (const float2 *)(f.ws + lay.o_b);
+    float2 *spec = (float2 *)(f.ws + lay.o_a);
+    uint32_t *nbits = (uint32_t *)(f.ws + lay.o_nb);
+    float2 *Xs = (float2 *)(f.ws + lay.o_x);
+    const float2 *tw = twpool + Pl->tw_off;
+    const uint32_t r = threadIdx.x;
+    const bool live = r < M1;
+    for (uint32_t e = r; e < M2; e += RT) w2[e] = tw[e * (M1 * f.sc)];
+    float2 z[M2];  // in: point n2 = P u + v at [P u + v]; after the transform: bin k2 = ku + 9 kv at [ku + 9 kv]
+#pragma unroll
+    for (uint32_t j = 0; j < M2; ++j) z[j] = live ? Y[r * M2 + j] : make_float2(0.0f, 0.0f);
+    __syncthreads();  // w2
+    {
+        float2 c[9][P];  // [ku][v]
+#pragma unroll
+        for (int v = 0; v < P; ++v) {
+            float2 b[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) b[u] = z[P * u + v];
+            dft9f(b);
+#pragma unroll
+            for (int ku = 0; ku < 9; ++ku) c[ku][v] = ku ? cmulc(b[ku], w2[v * ku]) : b[0];
+        }
+#pragma unroll
+        for (int ku = 0; ku < 9; ++ku) {
+            dft_pow2f<P>(c[ku]);
+#pragma unroll
+            for (int kv = 0; kv < P; ++kv) z[ku + 9 * kv] = c[ku][kv];
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < M2; ++k2) T[k2 * TS + r] = z[k2];
+    }
+    __syncthreads();
+    if (!live) return;
+    const bool dense = !(sparse_inv && Pl->sp_mf);
+    uint32_t zeros = 0;
+    auto finish = [&](uint32_t k, float2 v) {
+        spec[k] = v;
+        nbits[k] = __float_as_uint((float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y));
+        zeros += (v.x != 0.0f || v.y != 0.0f) ? 0u : 1u;
+        if (dense) Xs[k] = make_float2(0.0f, 0.0f);
+    };
+    auto untangle = [&](float2 zk, float2 zm, float2 wk) -> float2 {  // as k_large_rows9p
+        const float2 a = make_float2(zk.x + zm.x, zk.y - zm.y);
+        const float2 bb = make_float2(zk.x - zm.x, zk.y + zm.y);
+        const float2 t = cmulc(make_float2(bb.y, -bb.x), wk);
+        return make_float2(0.5f * a.x + 0.5f * t.x, 0.5f * a.y + 0.5f * t.y);
+    };
+    // bin k = r + 243 k2 pairs with M - k = (243 - r) + 243 (M2 - 1 - k2)  (r >= 1);  row 0: M - k = 243 (M2 - k2)
+    const uint32_t pr = r ? M1 - r : 0u;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < M2; ++k2) {
+        const uint32_t pk2 = r ? (M2 - 1 - k2) : (k2 ? M2 - k2 : 0u);
+        const float2 zm = T[pk2 * TS + pr];
+        const uint32_t k = r + M1 * k2;
+        finish(k, untangle(z[k2], zm, tw[k]));  // (the untangle twiddle W_L^k: consecutive threads, consecutive entries)
+        if (k == 0) finish(M, untangle(z[0], z[0], tw[M]));
+    }
+    if (__ballot(zeros != 0)) {
+        zeros = wave_sum_u32(zeros);
+        if ((r & 63) == 0) atomicAdd((uint32_t *)(f.ws + lay.o_cnt), zeros);
+    }
+}
