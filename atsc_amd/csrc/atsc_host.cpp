@@ -985,7 +985,8 @@ static int ensure_chain(atsc_ctx *ctx, const atsc_plan *plan, uint32_t c, bool f
     atsc_plan::Chain &ch = plan->chains[q];  // set q (scratch, events), run on chain stream c
     if (!ctx->chain_streams[c]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->chain_streams[c], hipStreamNonBlocking));
     // (the pack stream is made when a call first packs on it: a process has a handful of hardware queues, the
-    // runtime deals streams over them, and a stream nobody uses still takes its turn in that deal)
+    // runtime deals streams over them, and a stream nobody uses still takes its turn in that deal -- made up front
+    // beside chain 0 it took four chains from 101 to 86 Gsamples/s)
     if (!ch.ev_fork) {
         HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_fork, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ch.ev_lfork, hipEventDisableTiming));
@@ -1102,7 +1103,11 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     // 10.5 M-sample batch, two chains: 115.5 us per step with packing streams, 106.4 without (104.8 with
     // GPU_MAX_HW_QUEUES=8 and packing streams, i.e. no sharing); tools/chain_stamp_probe.py shows the stalls.
     static const bool pack_same_env = getenv("ATSC_PACK_SAME_STREAM") != nullptr, pack_apart_env = getenv("ATSC_PACK_APART") != nullptr;
-    const bool pack_apart = pipelined && !pack_same_env && (pack_apart_env || plan_chains(ctx, plan) == 1);
+    // (a context that has run three or four chains and is then set to one keeps packing on the chain's stream: a pack
+    // stream created behind four chain streams was seen to serialise with chain 0 -- 176 instead of 113 us per step, and
+    // no cost order -- whatever GPU_MAX_HW_QUEUES said)
+    const bool pack_apart = pipelined && !pack_same_env &&
+                            (pack_apart_env || (plan_chains(ctx, plan) == 1 && (ctx->pack_streams[0] || !ctx->chain_streams[2])));
     bool codec_attached = false;  // ev_codec is the stop event of this call's last codec dispatch
     auto pack = [&]() -> int {
         for (uint32_t g = 0; g < large_groups; ++g)
