@@ -43,9 +43,12 @@ HEADERS = ["atsc_device.h", "atsc_internal.h", "atsc_large_cols.h", "atsc_large_
 CFLAGS = [f for f in FLAGS if f != "-shared"] + os.environ.get("ATSC_BUILD_DEFS", "").split()
 
 
-# per-source additions to CFLAGS
+# per-source additions to CFLAGS.  atsc_kernels.hip: no machine-level loop-invariant code motion -- in kernels this
+# long it hoists dozens of constant materialisations out of the frame's loops and keeps them in registers across
+# everything else (k_compress<1,5,false,256>: 32 -> 16 spilled SGPRs; 1-2 % on every frame length; the resident-workgroup
+# experiment does not fit its registers without it).  ATSC_BUILD_MLICM=1 builds with the compiler's default.
 FILE_FLAGS = {}
-if os.environ.get("ATSC_BUILD_NO_MLICM"):
+if not os.environ.get("ATSC_BUILD_MLICM"):
     FILE_FLAGS["atsc_kernels.hip"] = ["-mllvm", "-disable-machine-licm"]
 
 
