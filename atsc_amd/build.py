@@ -50,6 +50,9 @@ CFLAGS = [f for f in FLAGS if f != "-shared"] + os.environ.get("ATSC_BUILD_DEFS"
 FILE_FLAGS = {}
 if not os.environ.get("ATSC_BUILD_MLICM"):
     FILE_FLAGS["atsc_kernels.hip"] = ["-mllvm", "-disable-machine-licm"]
+for _f in os.environ.get("ATSC_BUILD_NOMLICM_ALSO", "").split(","):  # (A/B aid: the same for other sources)
+    if _f:
+        FILE_FLAGS[_f] = ["-mllvm", "-disable-machine-licm"]
 
 
 def _flags_key(src=None):
