@@ -91,19 +91,33 @@ def compare_frame(oracle, x, max_error, tag, payload, chosen_o, payload_o, repor
             if max(norms) - min(norms) > FFT_COEF_RTOL * scale:
                 return "FAIL:fft bin set differs %s" % sorted(diff)
             return "tie"  # different (tied) bins admitted: the reconstructions, hence the errors, differ"
-        dg = {p: (r, i) for p, r, i in fg}
-        for a, b in zip(pos_g, pos_o):
+        for (a, ra, ia), (b, rb, ib) in zip(fg, fo):
             if a != b:
-                na, nb = np.hypot(*dg[a]), np.hypot(*dg[b])
+                na, nb = np.hypot(ra, ia), np.hypot(rb, ib)
                 if abs(na - nb) > FFT_COEF_RTOL * scale:
                     return "FAIL:fft order"
-    dg = {p: (r, i) for p, r, i in fg}
-    for p, r, i in fo:
-        if p in dg:
-            rg, ig = dg[p]
+
+    # A stored position can occur twice: `pos as u16` (fft.rs:242) folds bin p + 65536 of a 131072-sample frame onto p,
+    # and a deep ladder admits both.  Entries are therefore matched by (position, occurrence), not by position alone.
+    def keyed(fr):
+        seen, out = {}, {}
+        for p, r, i in fr:
+            k = seen.get(p, 0)
+            seen[p] = k + 1
+            out[(p, k)] = (r, i)
+        return out
+
+    dg, do = keyed(fg), keyed(fo)
+    for key, (r, i) in do.items():
+        if key in dg:
+            rg, ig = dg[key]
             if abs(rg - r) > FFT_COEF_RTOL * scale or abs(ig - i) > FFT_COEF_RTOL * scale:
+                # the two occurrences of a folded position may have swapped (near-equal norms): try the other one
+                alt = dg.get((key[0], 1 - key[1])) if key[1] < 2 else None
+                if alt is not None and abs(alt[0] - r) <= FFT_COEF_RTOL * scale and abs(alt[1] - i) <= FFT_COEF_RTOL * scale:
+                    continue
                 return "FAIL:fft coef pos=%d gpu=(%r,%r) oracle=(%r,%r) scale=%r" % (
-                    p, rg, ig, r, i, scale)
+                    key[0], rg, ig, r, i, scale)
     return "tol"
 
 

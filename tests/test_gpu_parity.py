@@ -469,6 +469,23 @@ def test_auto_large_frames(ctx, A, oracle, sizes, klasses):
     _log(P.assert_summary(s, len(offs) - 1, "large frames %s classes %s codecs %s" % (sizes, klasses, s["codecs"])))
 
 
+def test_forced_fft_large_frames_with_folded_positions(ctx, A, oracle):
+    """Forced FFT on 131072-sample frames of a smooth class: the ladder stores a bin p and its `pos as u16` alias
+    p + 65536 (fft.rs:242), so a stored position occurs twice.  Found by tools/fuzz_soak.py (FUZZ_LARGE=2): the
+    comparison has to match entries by (position, occurrence) -- by position alone it held an entry against its alias."""
+    F = 131072
+    xs = [H.synth_series(900 + k, F, klass=c) for k, c in enumerate((2, 0, 2))]
+    x = np.concatenate(xs)
+    off = H.frame_offsets(len(x), F)
+    s = P.compare_batch(oracle, ctx, x, off, A.FFT, True, ME5)
+    dup = 0
+    for fs, sc, tag, payload in H.parse_bro_body(s["records"], with_count=False):
+        pos = [f[0] for f in H.parse_fft_payload(payload)[0]]
+        dup += len(pos) - len(set(pos))
+    assert dup >= 1, "the case this test is for: a folded position stored twice"
+    _log(P.assert_summary(s, 3, "forced FFT, 131072-sample frames with folded positions (%d duplicates)" % dup))
+
+
 def test_reference_chunker_long_series(ctx, A, oracle):
     """compress_data flow (main.rs:130-165) on a 300000-sample series: 131072, 131072, 32768,
     4096, 512, 480 -- every kernel tier in one batch, byte-compared at the stream level."""

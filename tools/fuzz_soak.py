@@ -21,9 +21,11 @@ for seed in seeds:
     me = float(np.float32(e) / np.float32(100))
     uniform = seed % 3 == 0
     xs, offs = [], [0]
-    large = os.environ.get("FUZZ_LARGE") == "1"  # frames of the large tier instead (fewer of them)
+    large = os.environ.get("FUZZ_LARGE") in ("1", "2")  # frames of the large tier instead (fewer of them)
+    # FUZZ_LARGE=2: only the chunker's power-of-two chunks (M = 243 x 9 P: the grid path of atsc_large_fast.h)
+    large_sizes = [8192, 16384, 32768, 65536, 131072] if os.environ.get("FUZZ_LARGE") == "2" else [4097, 5000, 6561, 8192, 12000, 20000, 32768, 40000]
     for _ in range(40 if large else 200):
-        n = int(rng.choice([4097, 5000, 6561, 8192, 12000, 20000, 32768, 40000])) if large else 256 if uniform else int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, 1024, 2048, 4096,
+        n = int(rng.choice(large_sizes)) if large else 256 if uniform else int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, 1024, 2048, 4096,
                                                 rng.integers(600, 4097)], p=[0.1, 0.35, 0.15, 0.05, 0.05, 0.05, 0.05, 0.05, 0.15]))
         xs.append(_fuzz_frame(rng, n))
         offs.append(offs[-1] + n)
