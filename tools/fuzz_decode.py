@@ -11,14 +11,15 @@ from tests.test_gpu_parity import _fuzz_frame
 orc.build()
 ctx = A.Context(0)
 seeds = range(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 130)
-large = os.environ.get("FUZZ_LARGE") == "1"
+large = os.environ.get("FUZZ_LARGE") in ("1", "2")  # 2: only the power-of-two chunks 8192 ... 131072 (the decoder's grid path)
+large_sizes = [8192, 16384, 32768, 65536, 131072] if os.environ.get("FUZZ_LARGE") == "2" else [4097, 5000, 6561, 8192, 12000, 20000, 32768, 40000]
 bad = 0; frames = 0; by_codec = {}
 for seed in seeds:
     rng = np.random.default_rng(seed)
     e = int(rng.choice([0, 1, 2, 3, 5, 10, 20, 50])); me = float(np.float32(e) / np.float32(100))
     xs, offs = [], [0]
     for _ in range(30 if large else 200):
-        n = int(rng.choice([4097, 5000, 6561, 8192, 12000, 20000, 32768, 40000])) if large else int(rng.choice(
+        n = int(rng.choice(large_sizes)) if large else int(rng.choice(
             [rng.integers(1, 40), rng.integers(40, 600), 256, 128, 512, 1024, 2048, 4096, rng.integers(600, 4097)],
             p=[0.1, 0.35, 0.15, 0.05, 0.05, 0.05, 0.05, 0.05, 0.15]))
         xs.append(_fuzz_frame(rng, n)); offs.append(offs[-1] + n)
