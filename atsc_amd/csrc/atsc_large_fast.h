@@ -220,16 +220,26 @@ DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t 
             z.im = myvv[u][q].y;
             zs[b + rank] = z;
         }
-    // the buckets by descending size (ties by index): the tiles deal them over their thread groups in this order
-    if (tid < FAST_MF) {
-        const uint32_t mine = cnt[tid];
+    // the buckets by descending size (ties by index): the tiles deal them over their thread groups in this order.
+    // Rank by counting, four threads per bucket (a quarter of the 243 compares each; one thread per bucket walked
+    // them all: 6 us of LDS round trips); the partial ranks meet in zl[], which is free once zs is built.
+    __syncthreads();
+    uint32_t *rk = (uint32_t *)zl;
+    if (tid < 256) rk[tid] = 0;
+    __syncthreads();
+    if (tid < 4 * FAST_MF) {
+        const uint32_t b = tid % FAST_MF, q = tid / FAST_MF;
+        const uint32_t mine = cnt[b];
+        const uint32_t t0 = q * 61u, t1 = min(FAST_MF, t0 + 61u);
         uint32_t rank = 0;
-        for (uint32_t t = 0; t < FAST_MF; ++t) {
+        for (uint32_t t = t0; t < t1; ++t) {
             const uint32_t o = cnt[t];
-            rank += (o > mine || (o == mine && t < tid)) ? 1u : 0u;
+            rank += (o > mine || (o == mine && t < b)) ? 1u : 0u;
         }
-        border[rank] = tid;
+        if (rank) atomicAdd(&rk[b], rank);
     }
+    __syncthreads();
+    if (tid < FAST_MF) border[rk[tid]] = tid;
     __syncthreads();
     {
         uint32_t *gl = (uint32_t *)(Bb + FAST_LIST_OFF);
