@@ -2530,7 +2530,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                       kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
                       (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
     if (fast) {
-        e = ensure_dyn_lds((const void *)k_large_decide1, FAST_D1_LDS);
+        e = ensure_dyn_lds((const void *)k_large_decide1, fast_d1_lds(fast_carve(pre->m2_max)));
         if (e != hipSuccess) return e;
         e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
         if (e != hipSuccess) return e;
