@@ -232,12 +232,13 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
     sizes = atsc_amd.chunk_sizes(n)
     off = np.cumsum([0] + sizes).astype(np.uint64)
     plan = ctx.plan(off)
-    outs = [plan.alloc_outputs(torch, dev) for _ in range(4)]
+    NO = 8  # one output set per batch in flight (up to four chains x two scratch sets)
+    outs = [plan.alloc_outputs(torch, dev) for _ in range(NO)]
     R = len(d_xs)
     for i in range(2):
         plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
     torch.cuda.synchronize()
-    reps = 8
+    reps = 40  # (the one synchronisation at the end is ~20 us: spread over enough calls not to show)
     t0 = time.perf_counter()
     for i in range(reps):
         plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
@@ -246,13 +247,13 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
     total = int(outs[0]["rec_off"][-1].item())
     body = outs[0]["body"][:total].cpu().numpy().tobytes()
     for i in range(8):
-        plan.compress(d_xs[i % R], outs[i % 4], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+        plan.compress(d_xs[i % R], outs[i % NO], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
     plan.join(stream)
     torch.cuda.synchronize()
-    reps = 16
+    reps = 80
     t0 = time.perf_counter()
     for i in range(reps):
-        plan.compress(d_xs[i % R], outs[i % 4], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
+        plan.compress(d_xs[i % R], outs[i % NO], atsc_amd.AUTO, True, me, 0, stream, pipelined=True)
     plan.join(stream)
     torch.cuda.synchronize()
     dt_pipe = (time.perf_counter() - t0) / reps
@@ -263,10 +264,10 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
         dp.decompress(d_body, d_out, stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(20):
         dp.decompress(d_body, d_out, stream)
     torch.cuda.synchronize()
-    dt_dec = (time.perf_counter() - t0) / 5
+    dt_dec = (time.perf_counter() - t0) / 20
     dp.close()
     plan.close()
     return {"frames": len(sizes), "frame_len": int(sizes[0]), "ratio": 8.0 * n / (total + 12),
