@@ -1822,6 +1822,14 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
     uint64_t out_off = 0;
     uint32_t last_n = 0, last_pi = 0;
     if (has_count) { H.frames.reserve(declared); H.cls.reserve(declared); }
+    else {
+        // no count in front (atsc_decompress_frames): room for a record per 64 bytes, so that the walk of a typical
+        // stream does not stop to move its tables (it doubles from there if the records are shorter)
+        const uint64_t guess = std::min<uint64_t>(body_len / 64 + 16, 1ull << 22);
+        H.frames.reserve(guess);
+        H.cls.reserve(guess);
+    }
+    int last_c = -1;
     while (has_count ? H.frames.size() < declared : pos < body_len) {
         HostRecord hr;
         if (!host_next_record(body, body_len, pos, hr)) { *why = "dplan_create: truncated frame record"; return ATSC_E_FORMAT; }
@@ -1840,7 +1848,8 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
         if (nout > MAX_FRAME) { *why = "dplan_create: frame longer than 131072 samples"; return ATSC_E_UNSUPPORTED; }
         const uint32_t n = (uint32_t)nout;
         uint32_t pi;
-        if (n == last_n) {  // streams are runs of equal frame lengths: skip the table lookup
+        const bool reused = (n == last_n);
+        if (reused) {  // streams are runs of equal frame lengths: skip the table lookup
             pi = last_pi;
         } else {
             auto it = H.tabs.by_n.find(n);
@@ -1855,8 +1864,9 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
             last_pi = pi;
         }
         const DevPlan &dp = H.tabs.plans[pi];
-        const int c = class_of(n, dp.L);
+        const int c = (reused && last_c >= 0) ? last_c : class_of(n, dp.L);
         if (c < 0) { *why = "dplan_create: frame class"; return ATSC_E_UNSUPPORTED; }
+        last_c = c;
         DevDFrame d;
         d.payload_off = pay;
         d.out_off = out_off;
@@ -2011,21 +2021,53 @@ static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t b
         fprintf(stderr, "[decompress] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    // The records start towards the device before the host walks them: from memory the caller registered
+    // (atsc_host_register) the copy runs beside the walk; from pageable memory the call returns once the bytes are staged,
+    // which is what the blocking copy behind the walk cost as well.
+    if (!ctx || !body) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (auto &ev : ctx->ev_copy) HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    uint8_t *d_body = nullptr;
+    {
+        hipError_t e0 = pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(body_len, 16));
+        if (e0 != hipSuccess) return fail(ctx, ATSC_E_HIP, "decompress_frames: record buffer", e0);
+        e0 = hipMemcpyAsync(d_body, body, body_len, hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e0 == hipSuccess) e0 = hipEventRecord(ctx->ev_copy[0], ctx->copy_stream);
+        if (e0 != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            pool_free(ctx, d_body);
+            return fail(ctx, ATSC_E_HIP, "decompress_frames: record copy", e0);
+        }
+    }
+    lap("h2d records (enqueue)");
     atsc_dplan *dp = nullptr;
     int rc = atsc_dplan_create(ctx, body, body_len, has_count, &dp);
     lap("dplan_create");
-    if (rc) return rc;
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->copy_stream);  // the copy still reads the caller's bytes
+        pool_free(ctx, d_body);
+        return rc;
+    }
     *out_n = dp->n_samples;
     double *host = out;
     if (!out) {
         // (big_alloc: the block the caller released last is handed out again, resident pages and all)
         host = (double *)big_alloc((dp->n_samples ? dp->n_samples : 1) * sizeof(double));
-        if (!host) { atsc_dplan_destroy(dp); return fail(ctx, ATSC_E_NOMEM, "decompress_frames: output"); }
+        if (!host) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            pool_free(ctx, d_body);
+            atsc_dplan_destroy(dp);
+            return fail(ctx, ATSC_E_NOMEM, "decompress_frames: output");
+        }
     } else if (dp->n_samples > out_cap) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        pool_free(ctx, d_body);
         atsc_dplan_destroy(dp);
         return fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap");
     }
-    uint8_t *d_body = nullptr;
     double *d_out = nullptr;
     int status = 0;
     hipError_t e = hipSuccess;
@@ -2034,22 +2076,21 @@ static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t b
         e = (call);                                           \
         if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
     } while (0)
-    FCHK(pool_alloc(ctx, (void **)&d_body, std::max<uint64_t>(body_len, 16)));
     FCHK(pool_alloc(ctx, (void **)&d_out, dp->n_samples * sizeof(double)));
     lap("alloc");
-    FCHK(hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice));
-    lap("h2d records");
+    FCHK(hipStreamWaitEvent(nullptr, ctx->ev_copy[0], 0));  // the decoders run behind the records' copy
     rc = atsc_decompress_plan_dev(ctx, dp, d_body, d_out, nullptr);
     if (rc) goto done;
-    FCHK(hipStreamSynchronize(nullptr));
-    lap("kernels");
+    lap("launches");
+    // (the status word first: a malformed payload leaves the caller's buffer untouched)
     FCHK(hipMemcpy(&status, dp->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (status) { rc = fail(ctx, ATSC_E_FORMAT, "decompress_frames: malformed payload"); goto done; }
-    lap("status");
+    lap("kernels + status");
     FCHK(hipMemcpy(host, d_out, dp->n_samples * sizeof(double), hipMemcpyDeviceToHost));
     lap("d2h samples");
 #undef FCHK
 done:
+    (void)hipStreamSynchronize(ctx->copy_stream);
     pool_free(ctx, d_body);
     pool_free(ctx, d_out);
     atsc_dplan_destroy(dp);
