@@ -121,6 +121,8 @@ struct atsc_ctx {
     uint64_t plan_stamp = 0;
     hipStream_t work_stream = nullptr;
     hipStream_t copy_stream = nullptr;             // host-to-device copies of the host-pointer entry points
+    hipStream_t d2h_stream = nullptr;              // ... and the records' way back, part by part (registered memory)
+    std::vector<hipEvent_t> ev_parts;              // "part g's records are packed"
     hipEvent_t ev_copy[2] = {nullptr, nullptr};    // "part g's samples are on the device"
 };
 
@@ -592,6 +594,8 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     ctx->plan_cache.clear();
     if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+    for (auto &ev : ctx->ev_parts) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->ev_copy)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1503,6 +1507,23 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     lap("plans");
     int rc = ATSC_OK;
     uint64_t piece = 2u << 20;  // samples per copy call
+    bool by_parts = false, parts_overflow = false;
+    if (!out_alloc && parts > 1 && body) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, samples) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipPointerGetAttributes(&at, body) == hipSuccess && at.type == hipMemoryTypeHost)
+            by_parts = getenv("ATSC_NO_D2H_PARTS") == nullptr;
+        else
+            (void)hipGetLastError();  // (unregistered memory is an answer, not an error)
+    }
+    if (by_parts) {
+        if (!ctx->d2h_stream && hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking) != hipSuccess) by_parts = false;
+        while (by_parts && ctx->ev_parts.size() < parts) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { by_parts = false; break; }
+            ctx->ev_parts.push_back(ev);
+        }
+    }
     if (const char *e2 = getenv("ATSC_H2D_PIECE_MB")) piece = (uint64_t)std::max(1, atoi(e2)) << 17;
     double *d_x = nullptr, *d_err = nullptr;
     uint8_t *d_body = nullptr, *d_ch = nullptr;
@@ -1546,9 +1567,27 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
                            d_off + pt[g].f0 + g, d_ch + pt[g].f0, d_err + pt[g].f0, ws, false,
                            d_off + n_frames + parts + g);
         if (rc) goto done;
+        if (by_parts) FCHK(hipEventRecord(ctx->ev_parts[g], ws));
         lap("  part launches");
     }
     lap("h2d + launches");
+    if (by_parts) {
+        // Registered caller memory: the uploads above are in flight and the host is free, so the records of part g go
+        // back as soon as part g is packed -- the link carries both directions at once -- and what trails the last
+        // upload is the last part's kernels and the last part's records (a fifth of them).
+        uint64_t prev_end = 0;
+        for (uint64_t g = 0; g < parts; ++g) {
+            FCHK(hipEventSynchronize(ctx->ev_parts[g]));
+            uint64_t end_g = 0;
+            FCHK(hipMemcpy(&end_g, d_off + n_frames + parts + g + 1, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            if (end_g > body_cap || end_g < prev_end) { parts_overflow = true; break; }
+            if (end_g > prev_end)
+                FCHK(hipMemcpyAsync(body + prev_end, d_body + prev_end, end_g - prev_end, hipMemcpyDeviceToHost, ctx->d2h_stream));
+            prev_end = end_g;
+        }
+        FCHK(hipStreamSynchronize(ctx->d2h_stream));
+        lap("records by parts");
+    }
     FCHK(hipStreamSynchronize(ws));
     lap("kernel tail");
     {
@@ -1567,7 +1606,7 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
         rc = fail(ctx, ATSC_E_CAPACITY, "compress_frames: body_cap");
         goto done;
     }
-    if (total) FCHK(hipMemcpy(body, d_body, total, hipMemcpyDeviceToHost));
+    if (total && !(by_parts && !parts_overflow)) FCHK(hipMemcpy(body, d_body, total, hipMemcpyDeviceToHost));
     if (rec_off) {
         h_off.resize(n_frames + parts);
         FCHK(hipMemcpy(h_off.data(), d_off, (n_frames + parts) * sizeof(uint64_t), hipMemcpyDeviceToHost));
