@@ -133,14 +133,16 @@ int atsc_compress_plan_dev(atsc_ctx *ctx, const atsc_plan *plan, const double *d
  * run over file after file).  Consecutive calls on a plan go round-robin over up to four *chains*
  * inside the plan: a stream owned by the context plus everything a batch in flight owns (payload
  * slots, results, scan scratch, large-tier workspace).  A call's kernels -- codecs and packing -- run on
- * its chain's stream, ordered after everything enqueued on `stream` before the call by one event, so
- * up to four batches are in flight on as many hardware queues: the gap a single queue leaves between
- * dependent launches (6-10 us here) and the slow refill of freed wave slots are hidden by the other
- * chains' kernels.  Results are those of atsc_compress_plan_dev, byte for byte.
- *   - A call may block the host until the batch that last used its chain (up to four calls
- *     earlier) has finished; nothing else is synchronised.
+ * its chain's stream, ordered after everything enqueued on `stream` before the call by one event (only
+ * when `stream` still has work in flight), and every chain has two scratch sets, so up to 2 x chains batches
+ * are queued or in flight: the gap a single queue leaves between dependent launches (6-10 us here) and the
+ * drain of a launch's last workgroups are covered by the other chains' kernels.  Results are those of
+ * atsc_compress_plan_dev, byte for byte.
+ *   - A call may block the host until the batch that last used its scratch set (2 x chains calls
+ *     earlier) has been packed; nothing else is synchronised.
  *   - The outputs of a call are complete once a stream has passed an atsc_plan_join enqueued
- *     after it (or after hipDeviceSynchronize).  Give the calls in flight their own output buffers.
+ *     after it (or after hipDeviceSynchronize).  Give the calls in flight their own output buffers:
+ *     2 x chains sets (eight always suffice).
  *   - d_samples is read by kernels on the context's streams, NOT in `stream` order: it must not be
  *     overwritten until a stream has passed an atsc_plan_input_release (or atsc_plan_join)
  *     enqueued after the call.  (atsc_compress_plan_dev reads it in `stream` order; the large tier's
