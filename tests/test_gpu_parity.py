@@ -469,6 +469,61 @@ def test_auto_large_frames(ctx, A, oracle, sizes, klasses):
     _log(P.assert_summary(s, len(offs) - 1, "large frames %s classes %s codecs %s" % (sizes, klasses, s["codecs"])))
 
 
+def test_host_calls_on_registered_memory_and_after_a_trim(ctx, A):
+    """atsc_host_register page-locks the caller's buffers: atsc_compress_frames then uploads by DMA and copies the
+    records back part by part beside the later uploads, atsc_decompress_frames enqueues the records' copy before the
+    host walks them -- the bytes and the decoded samples must be those of the same calls on pageable memory.
+    atsc_ctx_trim / atsc_release_caches give the retained memory back: the next calls rebuild what they need and
+    return the same bytes."""
+    import ctypes as C
+
+    from atsc_amd import capi
+
+    lib = capi.lib()
+    n = 1 << 23  # 32768 frames of 256: four parts in atsc_compress_frames
+    x = np.ascontiguousarray(H.synth_series(77, n))
+    off = H.frame_offsets(n, 256)
+    rec0, ro0, ch0, err0 = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+    out0 = ctx.decompress_host(rec0)
+    offc = np.ascontiguousarray(off, dtype=np.uint64)
+    nf = len(off) - 1
+    body = np.empty(len(rec0) + 4096, dtype=np.uint8)
+    dec = np.empty(n, dtype=np.float64)
+    recarr = np.frombuffer(rec0, dtype=np.uint8).copy()
+    bufs = [x, body, dec, recarr]
+    done = []
+    try:
+        for a in bufs:
+            capi.check(lib.atsc_host_register(C.c_void_p(a.ctypes.data), a.nbytes), ctx._h)
+            done.append(a)
+        for round_ in range(3):
+            blen = C.c_uint64()
+            capi.check(lib.atsc_compress_frames(
+                ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)), offc.ctypes.data_as(C.POINTER(C.c_uint64)), nf, A.AUTO, 1,
+                C.c_float(np.float32(ME5)), 0, body.ctypes.data_as(C.POINTER(C.c_uint8)), body.size, C.byref(blen),
+                None, None, None), ctx._h)
+            assert bytes(body[: blen.value]) == rec0, round_
+            on = C.c_uint64()
+            capi.check(lib.atsc_decompress_frames(
+                ctx._h, recarr.ctypes.data_as(C.POINTER(C.c_uint8)), len(rec0), 0,
+                dec.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(on)), ctx._h)
+            assert on.value == n and np.array_equal(dec, out0), round_
+            if round_ == 0:
+                capi.check(lib.atsc_ctx_trim(ctx._h), ctx._h)
+            elif round_ == 1:
+                lib.atsc_release_caches()
+        # a capacity one byte short is reported, not overrun (the part-by-part copy checks every part's end)
+        blen = C.c_uint64()
+        rc = lib.atsc_compress_frames(
+            ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)), offc.ctypes.data_as(C.POINTER(C.c_uint64)), nf, A.AUTO, 1,
+            C.c_float(np.float32(ME5)), 0, body.ctypes.data_as(C.POINTER(C.c_uint8)), len(rec0) - 1, C.byref(blen),
+            None, None, None)
+        assert rc == capi.E_CAPACITY, rc
+    finally:
+        for a in done:
+            lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
+
+
 def test_forced_fft_large_frames_with_folded_positions(ctx, A, oracle):
     """Forced FFT on 131072-sample frames of a smooth class: the ladder stores a bin p and its `pos as u16` alias
     p + 65536 (fft.rs:242), so a stored position occurs twice.  Found by tools/fuzz_soak.py (FUZZ_LARGE=2): the
