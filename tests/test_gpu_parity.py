@@ -803,6 +803,44 @@ def test_idw_one_131072_frame(ctx, A, oracle):
     assert s["tol"] == 0 and s["boundary"] == 0
 
 
+@pytest.mark.parametrize("chains", [1, 2, 4])
+def test_pipelined_chunker_framing_of_an_odd_length_series(ctx, A, chains):
+    """A series whose length is no power of two, cut by the reference chunker (optimizer/mod.rs:78-98): large frames of
+    several row dimensions (131072, 65536, ..., 8192 samples: the grid path per P), medium and small ones behind them.
+    Batch after batch through the pipelined entry point, over 1, 2 and 4 chains: every batch's bytes are those of
+    a plain call."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    n = 131072 + 65536 + 32768 + 16384 + 8192 + 4096 + 1024 + 256 + 77
+    sizes = A.chunk_sizes(n)
+    assert sizes[0] == 131072 and 8192 in sizes and len(sizes) >= 8, sizes
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    batches = [torch.from_numpy(H.synth_series(1700 + b, n, klass=b % 4)).to(dev) for b in range(5)]
+    plan = ctx.plan(off)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for d_x in batches:
+        plan.compress(d_x, o, A.AUTO, True, ME5, 0, stream)
+        torch.cuda.synchronize()
+        total = int(o["rec_off"][-1].item())
+        ref.append(o["body"][:total].cpu().numpy().tobytes())
+    ctx.set_chains(chains)
+    try:
+        rounds = 12
+        outs = [plan.alloc_outputs(torch, dev) for _ in range(rounds)]
+        for r in range(rounds):
+            plan.compress(batches[r % len(batches)], outs[r], A.AUTO, True, ME5, 0, stream, pipelined=True)
+        plan.join(stream)
+        torch.cuda.synchronize()
+        for r in range(rounds):
+            total = int(outs[r]["rec_off"][-1].item())
+            assert outs[r]["body"][:total].cpu().numpy().tobytes() == ref[r % len(batches)], (chains, r)
+    finally:
+        ctx.set_chains(2)
+
+
 def test_independent_chains_on_one_gpu(ctx, A):
     """Three chains -- a context, a plan and a stream each -- push batches through the pipelined entry point at the
     same time (bench.py's `value_chains`, INTEGRATION.md "Several chains on one GPU"): every batch's bytes are those
