@@ -1619,7 +1619,11 @@ static int compress_frames_impl(atsc_ctx *ctx, const double *samples, const uint
     if (err) FCHK(hipMemcpy(err, d_err, n_frames * sizeof(double), hipMemcpyDeviceToHost));
 #undef FCHK
 done:
-    if (rc) (void)hipStreamSynchronize(ws);  // nothing may still run on the blocks that go back to the pool
+    if (rc) {  // nothing may still run on the blocks that go back to the pool
+        (void)hipStreamSynchronize(ws);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        if (by_parts && ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
+    }
     if (rc && out_alloc && *out_alloc) { free(*out_alloc); *out_alloc = nullptr; }
     pool_free(ctx, d_x);
     pool_free(ctx, d_body);
