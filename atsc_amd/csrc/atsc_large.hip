@@ -2530,7 +2530,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                       kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
                       (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
     if (fast) {
-        e = ensure_dyn_lds((const void *)k_large_decide1, fast_d1_lds(fast_carve(pre->m2_max)));
+        e = ensure_dyn_lds(pre->m2_max >= FAST_MD ? (const void *)k_large_decide1_big : (const void *)k_large_decide1,
+                           fast_d1_lds(fast_carve(pre->m2_max)));
         if (e != hipSuccess) return e;
         e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
         if (e != hipSuccess) return e;
@@ -2564,8 +2565,12 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                               (int)kp.sparse_inv);
             }
             const FastCarve cv = fast_carve(pre->m2_max);
-            hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), fast_d1_lds(cv), s, samples, frames, ids + b0, plans,
-                               twpool, kp, slots, res, ws, ws_stride, cv);
+            if (pre->m2_max >= FAST_MD)
+                hipLaunchKernelGGL(k_large_decide1_big, dim3(nb), dim3(LT), fast_d1_lds(cv), s, samples, frames, ids + b0,
+                                   plans, twpool, kp, slots, res, ws, ws_stride, cv);
+            else
+                hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), fast_d1_lds(cv), s, samples, frames, ids + b0, plans,
+                                   twpool, kp, slots, res, ws, ws_stride, cv);
             e = launch_trip243<false, DevFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, samples, frames, ids + b0, plans, twpool,
                                                 ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
             if (e != hipSuccess) return e;

@@ -251,11 +251,14 @@ DEVI uint32_t fast_bucket(uint32_t K, EntryFn entry, const float2 *tw, uint32_t 
     return nlist;
 }
 
-__global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_large_decide1(
+// BIG: the launch holds 131072-sample frames, whose carve-up leaves one workgroup per CU anyway: 128 VGPRs a lane, and the
+// norm patterns of the counting pass stay in registers for the collection pass (one read of the 280 KB instead of two).
+template <bool BIG>
+__device__ __forceinline__ void large_decide1(
     const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
-    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams &prm,
     uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride,
-    const FastCarve cv)
+    const FastCarve &cv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
@@ -406,15 +409,24 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // ---- the K1 largest norms (fft.rs:231-257), as a set ----
     const uint32_t *nbits = (const uint32_t *)(ws + lay.o_nb);
     for (uint32_t i = tid; i < 2048; i += LT) { h2[i] = 0; dcnt[i] = 0; }
+    // the counting pass adds into four copies of the counters, one per lane & 3 (a spectrum's norms crowd into a few
+    // exponents: a wavefront's adds to one counter queue up in the LDS); cand[] is free until the collection pass
+    // (long frames only: a short frame's pass is over before the 8192 extra counters are cleared and folded)
+    const bool copies = bins >= 32768;
+    uint32_t *hc = copies ? (uint32_t *)cand : h2;
+    const uint32_t csh = copies ? 2u : 0u, cp = copies ? (tid & 3u) : 0u;
+    if (copies)
+        for (uint32_t i = tid; i < 8192; i += LT) hc[i] = 0;
     if (wrap)
         for (uint32_t i = tid; i < cv.own_n; i += LT) own[i] = 0ull;
     if (tid < 16) bc[tid] = 0;
     if (tid == 0) bc[4] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t nq = bins >> 2;  // whole uint4 groups (the norm-bit region is 256-byte aligned)
-    constexpr uint32_t QPT = 6;     // groups in flight per thread
+    constexpr uint32_t QPT = BIG ? 18 : 6;  // groups in flight per thread (BIG: the whole frame, 69 985 bins)
+    const bool keep = BIG && nq <= QPT * LT;
+    uint4 v[QPT];
     for (uint32_t q0 = 0; q0 < nq; q0 += QPT * LT) {
-        uint4 v[QPT];
 #pragma unroll
         for (uint32_t u = 0; u < QPT; ++u) {
             const uint32_t q = q0 + u * LT + tid;
@@ -424,15 +436,22 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (uint32_t u = 0; u < QPT; ++u) {
             const uint32_t q = q0 + u * LT + tid;
             if (q < nq) {
-                atomicAdd(&h2[2047u - (v[u].x >> 20)], 1u);
-                atomicAdd(&h2[2047u - (v[u].y >> 20)], 1u);
-                atomicAdd(&h2[2047u - (v[u].z >> 20)], 1u);
-                atomicAdd(&h2[2047u - (v[u].w >> 20)], 1u);
+                atomicAdd(&hc[((2047u - (v[u].x >> 20)) << csh) | cp], 1u);
+                atomicAdd(&hc[((2047u - (v[u].y >> 20)) << csh) | cp], 1u);
+                atomicAdd(&hc[((2047u - (v[u].z >> 20)) << csh) | cp], 1u);
+                atomicAdd(&hc[((2047u - (v[u].w >> 20)) << csh) | cp], 1u);
             }
         }
     }
-    for (uint32_t k = 4 * nq + tid; k < bins; k += LT) atomicAdd(&h2[2047u - (nbits[k] >> 20)], 1u);
+    for (uint32_t k = 4 * nq + tid; k < bins; k += LT) atomicAdd(&hc[((2047u - (nbits[k] >> 20)) << csh) | cp], 1u);
     __syncthreads();
+    if (copies) {
+        for (uint32_t i = tid; i < 2048; i += LT) {
+            const uint4 c4 = ((const uint4 *)hc)[i];
+            h2[i] = c4.x + c4.y + c4.z + c4.w;
+        }
+        __syncthreads();
+    }
     FSTAMP(2);  // 2: histogram
     {
         const uint32_t c0 = h2[2 * tid], c1 = h2[2 * tid + 1];
@@ -465,16 +484,20 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             }
         };
         for (uint32_t q0 = 0; q0 < nq; q0 += QPT * LT) {
-            uint4 v[QPT];
+            if (!keep) {
 #pragma unroll
-            for (uint32_t u = 0; u < QPT; ++u) {
-                const uint32_t q = q0 + u * LT + tid;
-                v[u] = q < nq ? ((const uint4 *)nbits)[q] : make_uint4(0, 0, 0, 0);
+                for (uint32_t u = 0; u < QPT; ++u) {
+                    const uint32_t q = q0 + u * LT + tid;
+                    v[u] = q < nq ? ((const uint4 *)nbits)[q] : make_uint4(0, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < QPT; ++u) {
                 const uint32_t q = q0 + u * LT + tid;
                 const bool in = q < nq;
+                // the large norms sit together (low frequencies): most wavefronts see four values below the digit
+                const uint32_t top = max(max(v[u].x, v[u].y), max(v[u].z, v[u].w)) >> 20;
+                if (!__ballot(in && top >= dstar)) continue;
                 visit(4 * q, v[u].x, in);
                 visit(4 * q + 1, v[u].y, in);
                 visit(4 * q + 2, v[u].z, in);
@@ -604,6 +627,24 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     FSTAMP(7);  // 7: list and state out
     FSTAMP_PRINT("decide1");
+}
+
+__global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_large_decide1(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
+    uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+    const FastCarve cv)
+{
+    large_decide1<false>(samples, frames, ids, plans, twpool, prm, slots, res, ws_base, ws_stride, cv);
+}
+
+__global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_large_decide1_big(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, const KParams prm,
+    uint8_t *__restrict__ slots, DevResult *__restrict__ res, unsigned char *__restrict__ ws_base, uint64_t ws_stride,
+    const FastCarve cv)
+{
+    large_decide1<true>(samples, frames, ids, plans, twpool, prm, slots, res, ws_base, ws_stride, cv);
 }
 
 // One tile (16 output columns jb) of the first FFT trip of one frame: F[288 ja + jb] for every ja, compared with the
