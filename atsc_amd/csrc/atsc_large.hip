@@ -1285,6 +1285,8 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     int mode = prm.mode;
     // behind the fast path (atsc_large_fast.h): only the frames it left undecided
     if (PART == 0 && prm.fast_skip && ((const FastState *)(ws + lay.o_front))->status == 2) return;
+    if (PART == 0 && prm.fast_skip && prm.debug_stop <= -3 && tid == 0)
+        printf("FASTLEFT frame %u why %u\n", fid, *(const uint32_t *)(ws + lay.o_front + 200));
 
     auto gpad = [&](uint32_t j) -> double {  // fft.rs:184-204
         int32_t i = (int32_t)j - (int32_t)pre;

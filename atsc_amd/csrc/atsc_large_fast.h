@@ -270,6 +270,9 @@ __device__ __forceinline__ void large_decide1(
     const LargeWs lay = large_ws_layout(n, L, P.kcap);
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
+    // why a frame was left to the general kernel (read back under ATSC_DEBUG_STOP=-3 / -4 only)
+#define FAST_WHY(c) do { if (tid == 0) *(uint32_t *)(ws + lay.o_front + 200) = (c); } while (0)
+    FAST_WHY(0);
     // ATSC_DEBUG_STOP=-3: workgroup 0 prints the 100 MHz clock at its phase boundaries when it ends
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define FSTAMP(i) do { if (prm.debug_stop <= -3) stamp[i] = wall_clock64(); } while (0)
@@ -280,7 +283,7 @@ __device__ __forceinline__ void large_decide1(
     FSTAMP(0);
     const FastGeo geo = fast_geo(P);
     const bool wrap = bins > 65536;  // `pos as u16` (fft.rs:242) can fold two bins onto one stored position
-    if (!geo.ok || (wrap && bins - 65536 > cv.own_n) || P.mf > cv.k_max || 3 * P.mf > cv.own_n || 3 * P.mf > cv.cand_max) return;
+    if (!geo.ok || (wrap && bins - 65536 > cv.own_n) || P.mf > cv.k_max || 3 * P.mf > cv.own_n || 3 * P.mf > cv.cand_max) { FAST_WHY(1); return; }
     // LDS: [wsum 80][bc 64][red 256][h2 2048 u32][dcnt 2048 u32][own cv.own_n u64][above cv.k_max u64][sorted cv.k_max u64]
     // [cand cv.cand_max u64]  (the launch's carve-up, fast_carve: sized for its longest frame)
     uint32_t *wsum = (uint32_t *)smem;
@@ -331,9 +334,9 @@ __device__ __forceinline__ void large_decide1(
         st = frame_stats(ws, lay, false, 0);
     }
     const double x0 = xs[0];
-    if (!(x0 == x0)) return;  // a NaN first sample keeps the scan's start value: left to the general kernel
+    if (!(x0 == x0)) { FAST_WHY(2); return; }  // a NaN first sample keeps the scan's start value: left to the general kernel
     const double smin = st.mn, smax = st.mx;
-    if (smin == 0.0 || smax == 0.0) return;  // the first zero of either sign has to be looked up
+    if (smin == 0.0 || smax == 0.0) { FAST_WHY(3); return; }  // the first zero of either sign has to be looked up
     uint32_t bitdepth;
     {
         int64_t maxi, mini;
@@ -369,7 +372,7 @@ __device__ __forceinline__ void large_decide1(
 
     // ---- polynomial, first trip (polynomial.rs:209-277): the chunk sums of k_large_poly1, in chunk order ----
     const uint32_t pstep = P.pstep[0], pK = P.pK[0];
-    if (!(pstep >= 16 && pstep <= 256 && pK >= 2)) return;
+    if (!(pstep >= 16 && pstep <= 256 && pK >= 2)) { FAST_WHY(4); return; }
     if (tid == 0) {
         double s = 0.0;
         const double *part = (const double *)(ws + lay.o_part);
@@ -393,13 +396,13 @@ __device__ __forceinline__ void large_decide1(
 
     // ---- FFT (fft.rs:288-362) ----
     const float mxf = (float)smax, mnf = (float)smin;
-    if (mxf == mnf) return;
+    if (mxf == mnf) { FAST_WHY(5); return; }
     const uint32_t Z = bins - lst->zeros;
     const uint32_t K1 = min(P.mf, Z);
-    if (K1 < 8) return;
+    if (K1 < 8) { FAST_WHY(6); return; }
     if (!can_win(1 + vlen(K1) + 9 * K1 + 8, 0)) {
         // even the first trip's payload loses to the polynomial, which passes: no transform is evaluated at all
-        if (!(poly_final && pcur <= me) || can_win(rle_lb, 2)) return;
+        if (!(poly_final && pcur <= me) || can_win(rle_lb, 2)) { FAST_WHY(7); return; }
         fast_emit_poly(out, res[fid], xs, n, bitdepth, pK, pstep, smin, smax, pcur, h2, wsum);
         if (tid == 0) fs->status = 2;
         return;
@@ -462,9 +465,9 @@ __device__ __forceinline__ void large_decide1(
         if (a1 < K1 && a1 + c1 >= K1) { bc[4] = 2 * tid + 1; bc[5] = a1; bc[6] = c1; }
         __syncthreads();
     }
-    if (bc[4] == 0xFFFFFFFFu) return;
+    if (bc[4] == 0xFFFFFFFFu) { FAST_WHY(8); return; }
     const uint32_t dstar = 2047u - bc[4], n_above = bc[5], n_cand = bc[6];
-    if (n_cand > cv.cand_max) return;
+    if (n_cand > cv.cand_max) { FAST_WHY(9); return; }
     {
         const uint32_t lane = tid & 63u;
         const uint64_t lt = (1ull << lane) - 1ull;
@@ -575,7 +578,7 @@ __device__ __forceinline__ void large_decide1(
             if (k37(key) <= prefix) above[atomicAdd(&bc[2], 1u)] = key;  // (the stretches live in sorted[] now)
         }
         __syncthreads();
-        if (bc[2] != take) return;  // (cannot happen: the select is exact)
+        if (bc[2] != take) { FAST_WHY(10); return; }  // (cannot happen: the select is exact)
         for (uint32_t i = tid; i < take; i += LT) {
             const unsigned long long key = above[i];
             uint32_t rank = 0;
@@ -993,10 +996,10 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     } else {
         // the ladder goes on with K2 bins: pruned only if that payload cannot beat a candidate that passes
         const uint32_t K2 = min(P.mf + P.dk1, f.Z);
-        if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) fs->status = 0; return; }
+        if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) fs->status = 0; FAST_WHY(11); return; }
     }
-    if (!f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; return; }
-    if (can_win(f.rle_lb, 2) || best_owner == 3) { if (tid == 0) fs->status = 0; return; }
+    if (!f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; FAST_WHY(12); return; }
+    if (can_win(f.rle_lb, 2) || best_owner == 3) { if (tid == 0) fs->status = 0; FAST_WHY(best_owner == 3 ? 14 : 13); return; }
     if (best_owner == 1) {
         fast_emit_poly(out, res[fid], xs, n, f.bitdepth, f.poly_K, f.poly_step, f.smin, f.smax, f.poly_err, aux, wsum);
     } else {
