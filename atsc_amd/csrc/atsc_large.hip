@@ -1286,7 +1286,10 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     // behind the fast path (atsc_large_fast.h): only the frames it left undecided
     if (PART == 0 && prm.fast_skip && ((const FastState *)(ws + lay.o_front))->status == 2) return;
     if (PART == 0 && prm.fast_skip && prm.debug_stop <= -3 && tid == 0)
-        printf("FASTLEFT frame %u why %u\n", fid, *(const uint32_t *)(ws + lay.o_front + 200));
+    {
+        const uint32_t *d = (const uint32_t *)(ws + lay.o_front + 200);
+        printf("FASTLEFT frame %u why %u  | %u %u %u %u %x %x %u %u %u\n", fid, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9]);
+    }
 
     auto gpad = [&](uint32_t j) -> double {  // fft.rs:184-204
         int32_t i = (int32_t)j - (int32_t)pre;

@@ -302,6 +302,16 @@ __device__ __forceinline__ void large_decide1(
     // ---- statistics (k_large_stats, or the column tiles' and polynomial chunks' records): optimizer/utils.rs:39-113 ----
     LargeStats *lst = (LargeStats *)(ws + lay.o_cnt);
     FrameStats st;
+    // (everything the verdicts below read from memory is asked for here, in one round trip: the first sample, the count of
+    // zero bins, the polynomial's chunk sums -- added in chunk order by one thread, polynomial.rs:209-277)
+    const double x0 = xs[0];
+    const uint32_t zero_bins = lst->zeros;
+    if (tid == 0) {
+        double s = 0.0;
+        const double *part = (const double *)(ws + lay.o_part);
+        for (uint32_t c = 0; c < (n + LCH - 1) / LCH; ++c) s += part[c];
+        bcd[0] = s / (double)n;
+    }
     if (prm.tile_stats) {
         // one record per lane, combined by wavefront reductions (nothing here depends on an order)
         double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
@@ -333,7 +343,6 @@ __device__ __forceinline__ void large_decide1(
     } else {
         st = frame_stats(ws, lay, false, 0);
     }
-    const double x0 = xs[0];
     if (!(x0 == x0)) { FAST_WHY(2); return; }  // a NaN first sample keeps the scan's start value: left to the general kernel
     const double smin = st.mn, smax = st.mx;
     if (smin == 0.0 || smax == 0.0) { FAST_WHY(3); return; }  // the first zero of either sign has to be looked up
@@ -373,12 +382,6 @@ __device__ __forceinline__ void large_decide1(
     // ---- polynomial, first trip (polynomial.rs:209-277): the chunk sums of k_large_poly1, in chunk order ----
     const uint32_t pstep = P.pstep[0], pK = P.pK[0];
     if (!(pstep >= 16 && pstep <= 256 && pK >= 2)) { FAST_WHY(4); return; }
-    if (tid == 0) {
-        double s = 0.0;
-        const double *part = (const double *)(ws + lay.o_part);
-        for (uint32_t c = 0; c < (n + LCH - 1) / LCH; ++c) s += part[c];
-        bcd[0] = s / (double)n;
-    }
     uint32_t vb = 0;
     if (bitdepth == 0 || bitdepth == 3) {
         vb = pK * (bitdepth == 0 ? 8u : 1u);
@@ -397,7 +400,7 @@ __device__ __forceinline__ void large_decide1(
     // ---- FFT (fft.rs:288-362) ----
     const float mxf = (float)smax, mnf = (float)smin;
     if (mxf == mnf) { FAST_WHY(5); return; }
-    const uint32_t Z = bins - lst->zeros;
+    const uint32_t Z = bins - zero_bins;
     const uint32_t K1 = min(P.mf, Z);
     if (K1 < 8) { FAST_WHY(6); return; }
     if (!can_win(1 + vlen(K1) + 9 * K1 + 8, 0)) {
@@ -549,13 +552,21 @@ __device__ __forceinline__ void large_decide1(
             __syncthreads();
             (void)block_excl_scan<LW>(h2, 2048, wsum);  // h2[i] = keys with a smaller digit
             const uint32_t a0 = h2[2 * tid], a1 = h2[2 * tid + 1];
-            if (c0 && a0 < remaining && a0 + c0 >= remaining) { bc[8] = 2 * tid; bc[9] = a0; }
-            if (c1 && a1 < remaining && a1 + c1 >= remaining) { bc[8] = 2 * tid + 1; bc[9] = a1; }
+            // (bc[7]: every key of the digit is taken -- the bits below do not matter)
+            if (c0 && a0 < remaining && a0 + c0 >= remaining) { bc[8] = 2 * tid; bc[9] = a0; bc[7] = (a0 + c0 == remaining) ? 1u : 0u; }
+            if (c1 && a1 < remaining && a1 + c1 >= remaining) { bc[8] = 2 * tid + 1; bc[9] = a1; bc[7] = (a1 + c1 == remaining) ? 1u : 0u; }
             __syncthreads();
             prefix |= (unsigned long long)bc[8] << sh;
             resolved |= (unsigned long long)dm << sh;
             remaining -= bc[9];
+            const bool whole = bc[7] != 0;
             __syncthreads();
+#ifndef ATSC_NO_SEL_EXIT
+            if (whole) {  // (distinct norms: the usual end, after the two levels that cover the norm's bits)
+                prefix |= (1ull << sh) - 1ull;
+                break;
+            }
+#endif
         }
         // keys are distinct: exactly `take` candidates have k37 <= prefix
     }
@@ -578,7 +589,15 @@ __device__ __forceinline__ void large_decide1(
             if (k37(key) <= prefix) above[atomicAdd(&bc[2], 1u)] = key;  // (the stretches live in sorted[] now)
         }
         __syncthreads();
-        if (bc[2] != take) { FAST_WHY(10); return; }  // (cannot happen: the select is exact)
+        if (bc[2] != take) {
+#ifdef ATSC_SEL_DEBUG
+            if (tid == 0) {
+                uint32_t *dbg = (uint32_t *)(ws + lay.o_front + 204);
+                dbg[0] = take; dbg[1] = bc[2]; dbg[2] = n_cand; dbg[3] = n_above; dbg[4] = (uint32_t)prefix; dbg[5] = (uint32_t)(prefix >> 32);
+                dbg[6] = bc[7]; dbg[7] = bc[8]; dbg[8] = bc[9];
+            }
+#endif
+            FAST_WHY(10); return; }  // (cannot happen: the select is exact)
         for (uint32_t i = tid; i < take; i += LT) {
             const unsigned long long key = above[i];
             uint32_t rank = 0;

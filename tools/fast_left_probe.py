@@ -26,6 +26,9 @@ chosen = []
 for l in r.stdout.splitlines():
     if l.startswith("FASTLEFT"):
         w = l.split(); left[int(w[2])] = int(w[4])
+        if os.environ.get("RAW"): print(l)
+    elif l.startswith("SELECT"):
+        print(l)
     elif l.startswith("CHOSEN"):
         chosen = [int(c) for c in l.split()[1:]]
 if not chosen:
