@@ -577,6 +577,9 @@ __device__ __forceinline__ void large_decide1(
     unsigned long long *skey = (unsigned long long *)(Bb + fast_keys_off(K1));
     const float2 *spec = (const float2 *)(ws + lay.o_a);
     uint32_t big = 0;
+    unsigned long long ad_key[2];
+    uint32_t ad_pos[2];
+    float2 ad_z[2];
     if (tid == 0) bc[2] = 0;
     __syncthreads();
     {
@@ -605,15 +608,21 @@ __device__ __forceinline__ void large_decide1(
             sorted[n_above + rank] = key;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < K1; i += LT) {
-            const unsigned long long key = sorted[i];
-            const uint32_t pos = (uint32_t)(key & 0xffffffffull);
-            const float2 z = spec[pos];
-            sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
-            skey[i] = key;
-            const uint32_t p16 = pos & 0xffffu;
-            big += p16 >= 251 ? 1u : 0u;
-            if (wrap && p16 < cv.own_n) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {  // (K1 <= 2 LT; entry i = tid + u LT stays in this thread's registers for the bucket builder)
+            const uint32_t i = tid + (uint32_t)u * LT;
+            ad_key[u] = 0ull; ad_pos[u] = 0; ad_z[u] = make_float2(0.0f, 0.0f);
+            if (i < K1) {
+                const unsigned long long key = sorted[i];
+                const uint32_t pos = (uint32_t)(key & 0xffffffffull);
+                const float2 z = spec[pos];
+                sel[i].pos = pos; sel[i].re = z.x; sel[i].im = z.y;
+                skey[i] = key;
+                ad_key[u] = key; ad_pos[u] = pos; ad_z[u] = z;
+                const uint32_t p16 = pos & 0xffffu;
+                big += p16 >= 251 ? 1u : 0u;
+                if (wrap && p16 < cv.own_n) atomicMax(&own[p16], key);  // the later admission (the larger key) owns the position
+            }
         }
     }
     {
@@ -626,11 +635,14 @@ __device__ __forceinline__ void large_decide1(
     // (the candidate list and the owners are done with once the points are formed: their LDS hosts the two list buffers)
     const uint32_t nlist = fast_bucket(
         K1,
-        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {
-            const Sel e = sel[i];
-            p = e.pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
-            if (wrap && p < cv.own_n && own[p] != skey[i]) return false;
-            x = (p == 0 || 2 * p == L) ? make_float2(e.re, 0.0f) : make_float2(e.re, e.im);
+        [&](uint32_t i, uint32_t &p, float2 &x) -> bool {  // (called with i = tid + u LT: this thread's own entries)
+            const bool hi = i >= LT;
+            const uint32_t e_pos = hi ? ad_pos[1] : ad_pos[0];
+            const float2 e_z = hi ? ad_z[1] : ad_z[0];
+            const unsigned long long e_key = hi ? ad_key[1] : ad_key[0];
+            p = e_pos & 0xffffu;  // `pos as u16` (fft.rs:242): bins >= 65536 are stored and mirrored 65536 lower
+            if (wrap && p < cv.own_n && own[p] != e_key) return false;
+            x = (p == 0 || 2 * p == L) ? make_float2(e_z.x, 0.0f) : e_z;
             return true;
         },
         tw, M, (SpEnt *)cand, (SpEnt *)own, h2, bc + 10, Bb, fast_bounds_off(K1));  // (own[] is read by entry() before zs is first written)
@@ -985,21 +997,20 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
     const LargeWs lay = large_ws_layout(n, L, P.kcap);
     FastState *fs = (FastState *)(ws + lay.o_front);
+    if (tid == 0) {  // the tiles' sums, in tile order (asked for together with the state: one round trip)
+        double s = 0.0;
+        const double *part = (const double *)(ws + lay.o_c + FAST_PARTIAL_OFF);
+        const uint32_t tiles = min(fast_geo(P).tiles, 32u);  // (18 at most for the frames this path serves)
+        for (uint32_t t = 0; t < tiles; ++t) s += part[t];
+        *(double *)(smem + 256) = s;
+    }
     if (fs->status != 1) return;
     const FastState f = *fs;
-    __syncthreads();
     uint32_t *wsum = (uint32_t *)smem;
     uint32_t *aux = (uint32_t *)(smem + 512);                       // 2048 u32
     const double *xs = samples + fr.sample_off;
     uint8_t *out = slots + fr.slot_off;
     const double me = prm.max_err;
-    if (tid == 0) {  // the tiles' sums, in tile order
-        double s = 0.0;
-        const double *part = (const double *)(ws + lay.o_c + FAST_PARTIAL_OFF);
-        const uint32_t tiles = fast_geo(P).tiles;
-        for (uint32_t t = 0; t < tiles; ++t) s += part[t];
-        *(double *)(smem + 256) = s;
-    }
     __syncthreads();
     const double cur = *(const double *)(smem + 256) / (double)L;  // mean over the padded samples (fft.rs:345)
     uint32_t best_size = f.best_size;
