@@ -524,6 +524,27 @@ def test_host_calls_on_registered_memory_and_after_a_trim(ctx, A):
             lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
 
 
+def test_large_grid_path_keeps_the_frames_it_can_decide():
+    """The grid path hands a frame back to the general kernel without a trace in the output -- the bytes are the same, the
+    call is 100 us to 2 ms slower -- so the hand-backs are counted here: under ATSC_DEBUG_STOP=-3 k_compress_large<0>
+    prints a reason code per frame it is left with (tools/fast_left_probe.py).  On the mixed workload at e = 5 % nothing
+    may come back for a reason other than 7 (a passing polynomial the RLE lower bound could still beat) or 11-14 (a ladder
+    that goes on), and codes 8-10 -- a select that misses its own count -- never."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for flen, nf in ((131072, 96), (16384, 256)):
+        env = dict(os.environ, NF=str(nf), FLEN=str(flen), RAW="1")
+        env.pop("ATSC_LARGE_NO_FAST", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fast_left_probe.py")], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-400:]
+        head = [l for l in r.stdout.splitlines() if l.startswith("frames ")]
+        assert head and int(head[0].split()[1]) == nf, r.stdout[-400:]
+        whys = [int(l.split()[4]) for l in r.stdout.splitlines() if l.startswith("FASTLEFT")]
+        assert all(w in (7, 11, 12, 13, 14) for w in whys), (flen, whys)
+        assert len(whys) <= nf // 16, (flen, whys)
+
+
 def test_forced_fft_large_frames_with_folded_positions(ctx, A, oracle):
     """Forced FFT on 131072-sample frames of a smooth class: the ladder stores a bin p and its `pos as u16` alias
     p + 65536 (fft.rs:242), so a stored position occurs twice.  Found by tools/fuzz_soak.py (FUZZ_LARGE=2): the
