@@ -408,6 +408,23 @@ static hipError_t launch_d(uint32_t count, uint32_t lds, const DevDFrame *frames
     return hipGetLastError();
 }
 
+// A small table from page-locked host memory into device memory by a kernel on the caller's stream instead of a copy
+// engine's queue: a synchronous hipMemcpy issued while a large device-to-host transfer is in flight waits behind it
+// (atsc_host.cpp: decompress_frames_halves).  src: a hipHostMalloc'd buffer (mapped into the device's address space).
+__global__ void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+hipError_t launch_copy_words(void *dst, const void *src_host_mapped, uint64_t n_words, hipStream_t s)
+{
+    if (n_words == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(512, (n_words + 255) / 256);
+    hipLaunchKernelGGL(k_copy_words, dim3(blocks), dim3(256), 0, s, (uint32_t *)dst, (const uint32_t *)src_host_mapped,
+                       n_words);
+    return hipGetLastError();
+}
+
 // frame classes as in the compressor (class_of, atsc_host.cpp): L <= 64 W SPL samples per workgroup
 hipError_t launch_decompress(const DevDFrame *frames, uint64_t n_frames, const uint32_t *ids, int cls,
                              uint32_t count, uint32_t lds, const DevPlan *plans,

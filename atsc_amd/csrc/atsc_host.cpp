@@ -45,6 +45,7 @@ hipError_t launch_pack(const DevFrame *frames, const DevResult *res, uint64_t n_
                        uint64_t body_cap, uint64_t *rec_off, uint8_t *chosen, double *err,
                        const uint32_t *big_ids, uint32_t n_big, hipStream_t s, uint64_t *chain = nullptr);
 hipError_t launch_nonfinite_flag(const double *x, uint64_t n, uint32_t *flag, hipStream_t s);
+hipError_t launch_copy_words(void *dst, const void *src_host_mapped, uint64_t n_words, hipStream_t s);
 hipError_t launch_decompress(const struct DevDFrame *frames, uint64_t n_frames, const uint32_t *ids,
                              int cls, uint32_t count, uint32_t lds, const DevPlan *plans,
                              const float2 *twpool, const uint8_t *body, double *out, int *status,
@@ -123,6 +124,8 @@ struct atsc_ctx {
     hipStream_t copy_stream = nullptr;             // host-to-device copies of the host-pointer entry points
     hipStream_t d2h_stream = nullptr;              // ... and the records' way back, part by part (registered memory)
     std::vector<hipEvent_t> ev_parts;              // "part g's records are packed"
+    unsigned char *h_stage = nullptr;              // page-locked staging for tables a kernel copies up (h2d_small)
+    size_t h_stage_cap = 0, h_stage_used = 0;
     hipEvent_t ev_copy[2] = {nullptr, nullptr};    // "part g's samples are on the device"
 };
 
@@ -519,14 +522,27 @@ static int build_plan_entry(uint32_t n, PlanTables &T, std::map<uint32_t, uint64
     return ATSC_OK;
 }
 
-static int upload_tables(atsc_ctx *ctx, PlanTables &T)
+// A table's way to the device.  up == nullptr: a synchronous copy.  Otherwise the bytes are staged in the context's
+// page-locked buffer and a kernel on `up` copies them (launch_copy_words): for a plan built while a large transfer to the
+// host is in flight, whose copy-engine queue a synchronous hipMemcpy would wait behind (0.5 ms behind 42 MB).  The staging
+// buffer is handed out front to back; the caller resets h_stage_used when no such kernel can be pending any more.
+static hipError_t h2d_small(atsc_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t up)
+{
+    if (bytes == 0) return hipSuccess;
+    if (up && (bytes & 3u) == 0 && ctx->h_stage && ctx->h_stage_used + bytes + 256 <= ctx->h_stage_cap) {  // (the last 256 bytes: status words)
+        unsigned char *st = ctx->h_stage + ctx->h_stage_used;
+        memcpy(st, src, bytes);
+        ctx->h_stage_used += (bytes + 255) & ~(size_t)255;
+        return launch_copy_words(dst, st, bytes / 4, up);
+    }
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+static int upload_tables(atsc_ctx *ctx, PlanTables &T, hipStream_t up = nullptr)
 {
     HIPCHK(ctx, pool_alloc(ctx, (void **)&T.d_plans, std::max<size_t>(1, T.plans.size()) * sizeof(DevPlan)));
-    HIPCHK(ctx, hipMemcpy(T.d_plans, T.plans.data(), T.plans.size() * sizeof(DevPlan),
-                          hipMemcpyHostToDevice));
+    HIPCHK(ctx, h2d_small(ctx, T.d_plans, T.plans.data(), T.plans.size() * sizeof(DevPlan), up));
     HIPCHK(ctx, pool_alloc(ctx, (void **)&T.d_tw, std::max<size_t>(1, T.twpool.size()) * sizeof(float2)));
-    HIPCHK(ctx, hipMemcpy(T.d_tw, T.twpool.data(), T.twpool.size() * sizeof(float2),
-                          hipMemcpyHostToDevice));
+    HIPCHK(ctx, h2d_small(ctx, T.d_tw, T.twpool.data(), T.twpool.size() * sizeof(float2), up));
     return ATSC_OK;
 }
 static void free_tables(atsc_ctx *ctx, PlanTables &T)
@@ -596,6 +612,7 @@ extern "C" void atsc_ctx_destroy(atsc_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     for (auto &ev : ctx->ev_parts) (void)hipEventDestroy(ev);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto &ev : ctx->ev_copy)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &pr : ctx->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1950,14 +1967,16 @@ extern "C" int atsc_internal_dplan_parse(const uint8_t *body, uint64_t body_len,
 }
 
 static int dplan_create_range(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count, uint64_t begin,
-                              uint64_t soft_limit, uint64_t *end_pos, atsc_dplan **out);
+                              uint64_t soft_limit, uint64_t *end_pos, atsc_dplan **out, hipStream_t up = nullptr);
 extern "C" int atsc_dplan_create(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
                                  int has_count, atsc_dplan **out)
 {
     return dplan_create_range(ctx, body, body_len, has_count, 0, ~0ull, nullptr, out);
 }
+// up: the stream a kernel copies the plan's tables up on instead of synchronous copies (h2d_small); the plan may then
+// only be used on that stream (or behind it)
 static int dplan_create_range(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count, uint64_t begin,
-                              uint64_t soft_limit, uint64_t *end_pos, atsc_dplan **out)
+                              uint64_t soft_limit, uint64_t *end_pos, atsc_dplan **out, hipStream_t up)
 {
     ATSC_API_BEGIN
     if (!ctx || !body || !out) return fail(ctx, ATSC_E_INVALID, "dplan_create: null argument");
@@ -2012,7 +2031,7 @@ static int dplan_create_range(atsc_ctx *ctx, const uint8_t *body, uint64_t body_
         if (getenv("ATSC_LARGE_DECODE_ONE_KERNEL")) p->large_sp_tiles = 0;
     }
     lap("class lists");
-    int rc = upload_tables(ctx, p->tabs);
+    int rc = upload_tables(ctx, p->tabs, up);
     if (rc) { atsc_dplan_destroy(p); return rc; }
     lap("tables up");
 #define PCHK(call)                                                                      \
@@ -2021,11 +2040,12 @@ static int dplan_create_range(atsc_ctx *ctx, const uint8_t *body, uint64_t body_
         if (e__ != hipSuccess) { atsc_dplan_destroy(p); return fail(ctx, ATSC_E_HIP, #call, e__); } \
     } while (0)
     PCHK(pool_alloc(ctx, (void **)&p->d_frames, frames.size() * sizeof(DevDFrame)));
-    PCHK(hipMemcpy(p->d_frames, frames.data(), frames.size() * sizeof(DevDFrame), hipMemcpyHostToDevice));
+    PCHK(h2d_small(ctx, p->d_frames, frames.data(), frames.size() * sizeof(DevDFrame), up));
     PCHK(pool_alloc(ctx, (void **)&p->d_ids, ids.size() * sizeof(uint32_t)));
-    PCHK(hipMemcpy(p->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PCHK(h2d_small(ctx, p->d_ids, ids.data(), ids.size() * sizeof(uint32_t), up));
     PCHK(pool_alloc(ctx, (void **)&p->d_status, sizeof(int)));
-    PCHK(hipMemset(p->d_status, 0, sizeof(int)));
+    if (up) PCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), up));
+    else PCHK(hipMemset(p->d_status, 0, sizeof(int)));
     if (p->class_count[CLASS_LARGE]) {
         p->ws_slots = std::min<uint32_t>(p->class_count[CLASS_LARGE], large_ws_slots(p->ws_stride));
         PCHK(pool_alloc(ctx, (void **)&p->d_ws, p->ws_stride * p->ws_slots));
@@ -2065,12 +2085,15 @@ extern "C" int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, con
 }
 
 // atsc_decompress_frames into memory the caller registered (atsc_host_register), for a stream without a count in
-// front: in two halves.  The samples' way back is the call (84 MB: 1.5 ms) and the host's walk over the record headers
-// is the largest part of the rest (0.2-0.3 ms for 40960 records: sequential, each header locates the next); with a
-// page-locked destination the copy of the first half's samples is a DMA transfer the host does not wait behind, so the
-// second half is walked, uploaded and decoded meanwhile.  d_body: the records, on their way to the device (ev_copy[0]).
-// Returns -1 when the form does not apply (the caller goes on with one plan), else the call's result; on an error the
-// caller's buffer may hold the first half's samples.
+// front: in parts (six; ATSC_DECODE_PARTS).  The samples' way back is the call (84 MB: 1.58 ms at the link's 53 GB/s) and
+// the host's walk over the record headers is the largest part of the rest (0.15-0.35 ms for 40960 records: sequential,
+// each header locates the next); with a page-locked destination a part's samples are a DMA transfer the host does not
+// wait behind, so the next part is walked, uploaded and decoded meanwhile.  Two things keep the copy engine fed: the first
+// part is short (a sixteenth of the records: the engine starts 0.1 ms into the call), and a part's tables go up by a
+// kernel on the work stream from page-locked staging (h2d_small) -- a synchronous hipMemcpy issued while samples are on
+// their way back waited 0.5 ms behind them.  The parts' status words follow their samples into the same staging buffer.
+// d_body: the records, on their way to the device (ev_copy[0]).  Returns -1 when the form does not apply (the caller goes
+// on with one plan), else the call's result; on an error the caller's buffer may hold the first parts' samples.
 static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, const uint8_t *d_body,
                                     double *out, uint64_t out_cap, uint64_t *out_n)
 {
@@ -2085,18 +2108,37 @@ static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t
     }
     if (!ctx->work_stream && hipStreamCreateWithFlags(&ctx->work_stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (!ctx->d2h_stream && hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking) != hipSuccess) return -1;
-    while (ctx->ev_parts.size() < 2) {
+    static const int n_parts_env = getenv("ATSC_DECODE_PARTS") ? atoi(getenv("ATSC_DECODE_PARTS")) : 0;
+    constexpr int MAXP = 8;
+    const int NP = n_parts_env >= 2 ? std::min(n_parts_env, MAXP) : 6;
+    while (ctx->ev_parts.size() < (size_t)NP) {
         hipEvent_t ev;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1;
         ctx->ev_parts.push_back(ev);
     }
     hipStream_t ws = ctx->work_stream, ds = ctx->d2h_stream;
-    atsc_dplan *dp[2] = {nullptr, nullptr};
-    double *d_o[2] = {nullptr, nullptr};
-    uint64_t n[2] = {0, 0}, end_a = 0;
-    int rc = dplan_create_range(ctx, body, body_len, 0, 0, body_len / 2, &end_a, &dp[0]);
+    static const bool no_kernel_up = getenv("ATSC_NO_KERNEL_UPLOAD") != nullptr;
+    if (!ctx->h_stage && !no_kernel_up) {  // the parts' tables: 32-byte frame records, ids, plans, twiddles
+        const size_t cap = 8u << 20;
+        if (hipHostMalloc((void **)&ctx->h_stage, cap, hipHostMallocDefault) == hipSuccess) ctx->h_stage_cap = cap;
+        else { ctx->h_stage = nullptr; (void)hipGetLastError(); }
+    }
+    ctx->h_stage_used = 0;  // (every earlier call ended with its streams drained)
+    hipStream_t up = no_kernel_up ? nullptr : ws;
+    volatile int *h_status = ctx->h_stage ? (volatile int *)(ctx->h_stage + ctx->h_stage_cap - 256) : nullptr;
+    atsc_dplan *dp[MAXP] = {};
+    double *d_o[MAXP] = {};
+    uint64_t n[MAXP] = {}, done_n = 0, pos = 0;
+    int used = 0;
+    // the first part: if one record holds everything behind it there is nothing to split
+    // a short first part -- the copy engine starts after its walk, upload and decode -- and even ones behind it (each is
+    // walked while its predecessor's samples travel: the walk is four to five times faster than the link)
+    static const int first_div = getenv("ATSC_DECODE_FIRST") ? std::max(2, atoi(getenv("ATSC_DECODE_FIRST"))) : 16;
+    const uint64_t lim0 = body_len / (uint64_t)std::max(first_div, NP);
+    int rc = dplan_create_range(ctx, body, body_len, 0, 0, lim0, &pos, &dp[0], up);
     if (rc) return rc;
-    if (end_a >= body_len) {  // (one record holds the second half: nothing to split)
+    if (pos >= body_len) {
+        (void)hipStreamSynchronize(ws);  // (its tables may still be on their way up)
         atsc_dplan_destroy(dp[0]);
         return -1;
     }
@@ -2107,34 +2149,44 @@ static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t
         if (e != hipSuccess) { rc = fail(ctx, ATSC_E_HIP, #call, e); goto done; } \
     } while (0)
     HCHK(hipStreamWaitEvent(ws, ctx->ev_copy[0], 0));  // the decoders run behind the records' copy
-    for (int h = 0; h < 2; ++h) {
-        if (h == 1) {
-            rc = dplan_create_range(ctx, body, body_len, 0, end_a, ~0ull, nullptr, &dp[1]);
+    for (int h = 0; h < NP; ++h) {
+        if (h >= 1) {
+            if (pos >= body_len) break;
+            // (its tables go up by a kernel on ws: the earlier parts' samples occupy the copy engine)
+            const uint64_t lim = h == NP - 1 ? ~0ull : lim0 + (body_len - lim0) / (uint64_t)(NP - 1) * (uint64_t)h;
+            rc = dplan_create_range(ctx, body, body_len, 0, pos, lim, h == NP - 1 ? nullptr : &pos, &dp[h], up);
             if (rc) goto done;
+            if (h == NP - 1) pos = body_len;
         }
+        used = h + 1;
         n[h] = dp[h]->n_samples;
-        if (n[0] + n[1] > out_cap) { rc = fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap"); goto done; }
-        HCHK(pool_alloc(ctx, (void **)&d_o[h], n[h] * sizeof(double)));
+        if (done_n + n[h] > out_cap) { rc = fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap"); goto done; }
+        HCHK(pool_alloc(ctx, (void **)&d_o[h], std::max<uint64_t>(n[h], 1) * sizeof(double)));
         rc = atsc_decompress_plan_dev(ctx, dp[h], d_body, d_o[h], ws);
         if (rc) goto done;
         HCHK(hipEventRecord(ctx->ev_parts[h], ws));
         HCHK(hipStreamWaitEvent(ds, ctx->ev_parts[h], 0));
-        HCHK(hipMemcpyAsync(out + (h ? n[0] : 0), d_o[h], n[h] * sizeof(double), hipMemcpyDeviceToHost, ds));
+        if (n[h]) HCHK(hipMemcpyAsync(out + done_n, d_o[h], n[h] * sizeof(double), hipMemcpyDeviceToHost, ds));
+        // the part's status word rides behind its samples into the page-locked buffer's tail
+        if (h_status) { h_status[h] = -1; HCHK(hipMemcpyAsync((void *)&h_status[h], dp[h]->d_status, sizeof(int), hipMemcpyDeviceToHost, ds)); }
+        done_n += n[h];
     }
     HCHK(hipStreamSynchronize(ds));
-    for (int h = 0; h < 2; ++h) {
+    HCHK(hipStreamSynchronize(ws));
+    for (int h = 0; h < used; ++h) {
         int status = 0;
-        HCHK(hipMemcpy(&status, dp[h]->d_status, sizeof(int), hipMemcpyDeviceToHost));
+        if (h_status) status = h_status[h];
+        else HCHK(hipMemcpy(&status, dp[h]->d_status, sizeof(int), hipMemcpyDeviceToHost));
         if (status) { rc = fail(ctx, ATSC_E_FORMAT, "decompress_frames: malformed payload"); goto done; }
     }
-    *out_n = n[0] + n[1];
+    *out_n = done_n;
 #undef HCHK
 done:
     if (rc) {
         (void)hipStreamSynchronize(ws);
         (void)hipStreamSynchronize(ds);
     }
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < MAXP; ++h) {
         pool_free(ctx, d_o[h]);
         if (dp[h]) atsc_dplan_destroy(dp[h]);
     }
@@ -2178,7 +2230,7 @@ static int decompress_frames_impl(atsc_ctx *ctx, const uint8_t *body, uint64_t b
     if (out && !has_count) {
         const int hrc = decompress_frames_halves(ctx, body, body_len, d_body, out, out_cap, out_n);
         if (hrc != -1) {
-            lap("two halves");
+            lap("parts");
             (void)hipStreamSynchronize(ctx->copy_stream);
             pool_free(ctx, d_body);
             return hrc;

@@ -41,6 +41,7 @@ hipError_t launch_pack(const DevFrame *, const DevResult *, uint64_t, uint32_t *
 {
     return hipErrorNotSupported;
 }
+hipError_t launch_copy_words(void *, const void *, uint64_t, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_decompress(const struct DevDFrame *, uint64_t, const uint32_t *, int, uint32_t, uint32_t,
                              const DevPlan *, const float2 *, const uint8_t *, double *, int *, hipStream_t)
 {
