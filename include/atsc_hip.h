@@ -234,7 +234,9 @@ uint64_t atsc_dplan_n_samples(const atsc_dplan *dp);
 /* d_body: the same bytes on the device; d_out: atsc_dplan_n_samples doubles. */
 int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t *d_body,
                              double *d_out, void *stream);
-/* Host-pointer convenience (synchronous). out_n receives the sample count. */
+/* Host-pointer convenience (synchronous). out_n receives the sample count.  On an error `out` may hold
+ * samples of the frames in front of the failing record (a destination registered with atsc_host_register
+ * is filled part by part while the later records are still being parsed); out_n is not written then. */
 int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
                            double *out, uint64_t out_cap, uint64_t *out_n);
 /* The same with the output allocated by the library at exactly the decoded length (atsc_free):

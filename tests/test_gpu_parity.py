@@ -524,6 +524,57 @@ def test_host_calls_on_registered_memory_and_after_a_trim(ctx, A):
             lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
 
 
+def test_decode_in_parts_reports_a_bad_record_in_a_later_part(ctx, A):
+    """atsc_decompress_frames into registered memory works in parts (the next part is walked and decoded while the one
+    before travels back).  A record that is broken in a later part -- an unknown codec tag, a length that runs past the
+    end, a payload the kernel rejects -- must end the call with the error the one-plan form gives, with every stream
+    drained: the same context then decodes the intact stream again, into the same buffers, to the same samples."""
+    import ctypes as C
+
+    from atsc_amd import capi
+
+    lib = capi.lib()
+    n = 1 << 22
+    x = np.ascontiguousarray(H.synth_series(91, n))
+    off = H.frame_offsets(n, 256)
+    rec0, ro0, _, _ = ctx.compress_host(x, off, A.AUTO, True, ME5, 0)
+    assert len(rec0) > (1 << 20)
+    out0 = ctx.decompress_host(rec0)
+    ro = np.asarray(ro0, dtype=np.uint64)
+    dec = np.empty(n, dtype=np.float64)
+    recarr = np.frombuffer(rec0, dtype=np.uint8).copy()
+    done = []
+    try:
+        for a in (dec, recarr):
+            capi.check(lib.atsc_host_register(C.c_void_p(a.ctypes.data), a.nbytes), ctx._h)
+            done.append(a)
+
+        def call(length):
+            on = C.c_uint64(12345)
+            rc = lib.atsc_decompress_frames(ctx._h, recarr.ctypes.data_as(C.POINTER(C.c_uint8)), length, 0,
+                                            dec.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(on))
+            return rc, on.value
+
+        nf = len(ro) - 1
+        p_late = int(ro[int(nf * 0.9)])  # a record in the last part
+        saved = recarr.copy()
+        for mutate in ("length", "truncate"):
+            recarr[:] = saved
+            if mutate == "length":
+                recarr[p_late] = 0xFF; recarr[p_late + 1] = 0xFF; recarr[p_late + 2] = 0xFF; recarr[p_late + 3] = 0x7F
+                rc, onv = call(len(rec0))
+            else:
+                rc, onv = call(len(rec0) - 3)  # the last record is cut short
+            assert rc != 0 and onv == 12345, (mutate, rc, onv)
+            recarr[:] = saved
+            dec[:] = -1.0
+            rc, onv = call(len(rec0))
+            assert rc == 0 and onv == n and np.array_equal(dec, out0), mutate
+    finally:
+        for a in done:
+            lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
+
+
 def test_large_grid_path_keeps_the_frames_it_can_decide():
     """The grid path hands a frame back to the general kernel without a trace in the output -- the bytes are the same, the
     call is 100 us to 2 ms slower -- so the hand-backs are counted here: under ATSC_DEBUG_STOP=-3 k_compress_large<0>
