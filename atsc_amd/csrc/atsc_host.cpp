@@ -200,6 +200,8 @@ struct atsc_plan {
     };
     mutable Chain chains[8];  // two sets per chain stream: set q runs on stream q % (number of chains)
     mutable uint32_t turn = 0;
+    mutable bool single_set = false;  // memory allowed no second scratch set: pipelined calls reuse set 0
+    mutable uint32_t chain_cap = 0;  // most chains this plan's pipelined calls use (0: not decided yet; plan_chains)
     uint64_t slots_bytes = 0;
 };
 
@@ -1022,28 +1024,60 @@ static int ensure_chain(atsc_ctx *ctx, const atsc_plan *plan, uint32_t c, bool f
         ch.d_ws = plan->d_ws;
     }
     if (!full || ch.ready) return ATSC_OK;
+    // A set that cannot be built completely is taken apart again (its blocks would otherwise stay in pool_live with
+    // the pointers overwritten by the next attempt) and the caller goes on with fewer chains.
+    hipError_t e = hipSuccess;
+    // (test aid: ATSC_DEBUG_FAIL_SET=q lets the allocation of set q and of every later set fail half-way)
+    static const int fail_from = getenv("ATSC_DEBUG_FAIL_SET") ? atoi(getenv("ATSC_DEBUG_FAIL_SET")) : -1;
+    int taken = 0;
+    auto take = [&](void **dst, size_t bytes) {
+        if (e == hipSuccess && fail_from >= 0 && (int)q >= fail_from && ++taken == 3) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) e = pool_alloc(ctx, dst, bytes);
+    };
     if (q > 0) {
         const uint32_t nb = (uint32_t)((plan->n_frames + 1023) / 1024);
-        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_res, plan->n_frames * sizeof(DevResult)));
-        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_slots, plan->slots_bytes));
-        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_local, plan->n_frames * sizeof(uint32_t)));
-        HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.S.d_blocksum, (nb + 1) * sizeof(uint64_t)));
-        if (plan->ws_slots) HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_ws, plan->ws_stride * plan->ws_slots));
+        take((void **)&ch.S.d_res, plan->n_frames * sizeof(DevResult));
+        take((void **)&ch.S.d_slots, plan->slots_bytes);
+        take((void **)&ch.S.d_local, plan->n_frames * sizeof(uint32_t));
+        take((void **)&ch.S.d_blocksum, (nb + 1) * sizeof(uint64_t));
+        if (plan->ws_slots) take((void **)&ch.d_ws, plan->ws_stride * plan->ws_slots);
     }
-    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_cost, plan->n_frames * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMemset(ch.d_cost, 0, plan->n_frames * sizeof(uint32_t)));
-    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_bucket, plan->n_frames));
-    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_hist, 2 * 8 * 64 * sizeof(uint32_t)));
-    HIPCHK(ctx, pool_alloc(ctx, (void **)&ch.d_ids_adapt, plan->n_frames * sizeof(uint32_t)));
+    take((void **)&ch.d_cost, plan->n_frames * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ch.d_cost, 0, plan->n_frames * sizeof(uint32_t));
+    take((void **)&ch.d_bucket, plan->n_frames);
+    take((void **)&ch.d_hist, 2 * 8 * 64 * sizeof(uint32_t));
+    take((void **)&ch.d_ids_adapt, plan->n_frames * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (q > 0) {
+            pool_free(ctx, ch.S.d_res); pool_free(ctx, ch.S.d_slots); pool_free(ctx, ch.S.d_local);
+            pool_free(ctx, ch.S.d_blocksum); pool_free(ctx, ch.d_ws);
+            ch.S = atsc_plan::Scratch();
+            ch.d_ws = nullptr;
+        }
+        pool_free(ctx, ch.d_cost); pool_free(ctx, ch.d_bucket); pool_free(ctx, ch.d_hist); pool_free(ctx, ch.d_ids_adapt);
+        ch.d_cost = nullptr; ch.d_bucket = nullptr; ch.d_hist = nullptr; ch.d_ids_adapt = nullptr;
+        return fail(ctx, ATSC_E_NOMEM, "pipelined call: scratch set", e);
+    }
     ch.ready = true;
     return ATSC_OK;
 }
-// chains a plan's pipelined calls rotate over: the context's setting, fewer when four scratch sets would be huge
+// chains a plan's pipelined calls rotate over: the context's setting, fewer when the scratch sets behind them (two per
+// chain; chain 0's first is the plan's own) would take more than half of the device memory that is free when the plan
+// first asks, and fewer again after a set could not be allocated (plan->chain_cap).  INTEGRATION.md has the footprint.
 static uint32_t plan_chains(const atsc_ctx *ctx, const atsc_plan *plan)
 {
-    uint32_t nch = (uint32_t)ctx->n_chains;
-    while (nch > 1 && (plan->slots_bytes + plan->ws_stride * plan->ws_slots) * 2 * nch > (48ull << 30)) --nch;
-    return nch;
+    if (!plan->chain_cap) {
+        uint32_t cap = 4;  // (atsc_ctx_set_chains takes 1..4)
+        size_t free_b = 0, total_b = 0;
+        uint64_t budget = 48ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, free_b / 2);
+        else (void)hipGetLastError();
+        const uint64_t per_set = plan->slots_bytes + plan->ws_stride * plan->ws_slots + plan->n_frames * 48;
+        while (cap > 1 && per_set * (2 * cap - 1) > budget) --cap;
+        plan->chain_cap = cap;
+    }
+    return std::min<uint32_t>((uint32_t)ctx->n_chains, plan->chain_cap);
 }
 
 // Shared body of atsc_compress_plan_dev (pipelined == false: everything on `stream`, scratch set 0)
@@ -1075,16 +1109,26 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
     uint32_t ci = 0, qi = 0; // chain (stream), set (scratch + events)
     if (pipelined) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
-        const uint32_t nch = plan_chains(ctx, plan);
-        qi = plan->turn % (2 * nch);  // two sets per chain: a chain's stream always holds a queued batch
+        uint32_t nch = plan_chains(ctx, plan);
+        // (every set is built by the first pipelined call: an allocation of hundreds of megabytes is milliseconds, not
+        // something to meet in the middle of a stream of batches.  A set that does not fit halves the ambition: the
+        // sets built so far stay -- their batches may be in flight -- and the rotation goes over fewer of them; one
+        // chain's first set is the plan's own, so the call itself only fails when not even the cost records fit)
+        for (uint32_t q = 0; q < (plan->single_set ? 1u : 2 * nch); ++q) {
+            int rc = ensure_chain(ctx, plan, q % nch, true, q);
+            if (!rc) continue;
+            if (q == 0) return rc;  // (set 0 is the plan's own scratch: only its cost records were asked for)
+            // sets 0 .. q-1 exist: the most chains whose two sets each are among them; one set alone means every call
+            // waits for its predecessor's packing
+            ctx->last_error.clear();
+            nch = std::max<uint32_t>(1, q / 2);
+            plan->chain_cap = nch;
+            if (q == 1) plan->single_set = true;
+            break;
+        }
+        qi = plan->turn % (plan->single_set ? 1 : 2 * nch);  // two sets per chain: a chain's stream always holds a queued batch
         ci = qi % nch;
         plan->turn++;
-        // (every set is built by the first pipelined call: an allocation of hundreds of megabytes is milliseconds, not
-        // something to meet in the middle of a stream of batches)
-        for (uint32_t q = 0; q < 2 * nch; ++q) {
-            int rc = ensure_chain(ctx, plan, q % nch, true, q);
-            if (rc) return rc;
-        }
         atsc_plan::Chain &ch = plan->chains[qi];
         // The chain's previous batch owns this scratch set until its records are packed.  Its kernels precede this
         // call's on the chain's stream, but the large tier's groups run on the other chains' streams as well; waiting
@@ -1095,7 +1139,10 @@ static int compress_impl(atsc_ctx *ctx, const atsc_plan *plan, const double *d_s
         // Work the caller enqueued on `stream` before this call (the copy that brought d_samples, say) precedes the
         // call's kernels.  An event record plus a cross-stream wait cost ~6 us of queue time per batch on this system,
         // so they are only spent when `stream` still has work in flight.
-        if (hipStreamQuery(caller) != hipSuccess) {
+        const hipError_t busy = hipStreamQuery(caller);
+        if (busy != hipSuccess && busy != hipErrorNotReady)  // an invalid handle, a capturing stream, an earlier fault
+            return fail(ctx, ATSC_E_HIP, "pipelined call: hipStreamQuery(stream)", busy);
+        if (busy == hipErrorNotReady) {
             (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: the launchers read the last error
             HIPCHK(ctx, hipEventRecord(ch.ev_fork, caller));
             HIPCHK(ctx, hipStreamWaitEvent(s, ch.ev_fork, 0));
@@ -1889,7 +1936,9 @@ static int dplan_parse(const uint8_t *body, uint64_t body_len, int has_count, DP
     else {
         // no count in front (atsc_decompress_frames): room for a record per 64 bytes, so that the walk of a typical
         // stream does not stop to move its tables (it doubles from there if the records are shorter)
-        const uint64_t guess = std::min<uint64_t>(body_len / 64 + 16, 1ull << 22);
+        // (of the range this call walks, not of the whole body: the parts form walks a sixth at a time)
+        const uint64_t walk_end = std::min(soft_limit, body_len);
+        const uint64_t guess = std::min<uint64_t>((walk_end > begin ? walk_end - begin : 0) / 64 + 16, 1ull << 22);
         H.frames.reserve(guess);
         H.cls.reserve(guess);
     }
@@ -2129,7 +2178,6 @@ static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t
     atsc_dplan *dp[MAXP] = {};
     double *d_o[MAXP] = {};
     uint64_t n[MAXP] = {}, done_n = 0, pos = 0;
-    int used = 0;
     // the first part: if one record holds everything behind it there is nothing to split
     // a short first part -- the copy engine starts after its walk, upload and decode -- and even ones behind it (each is
     // walked while its predecessor's samples travel: the walk is four to five times faster than the link)
@@ -2154,11 +2202,13 @@ static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t
             if (pos >= body_len) break;
             // (its tables go up by a kernel on ws: the earlier parts' samples occupy the copy engine)
             const uint64_t lim = h == NP - 1 ? ~0ull : lim0 + (body_len - lim0) / (uint64_t)(NP - 1) * (uint64_t)h;
+            // a record longer than a part's stride (131072-sample Noop / RLE / deep FFT records) can end behind this
+            // part's limit: the part is then empty and the next one starts where the walk stands
+            if (pos >= lim) continue;
             rc = dplan_create_range(ctx, body, body_len, 0, pos, lim, h == NP - 1 ? nullptr : &pos, &dp[h], up);
             if (rc) goto done;
             if (h == NP - 1) pos = body_len;
         }
-        used = h + 1;
         n[h] = dp[h]->n_samples;
         if (done_n + n[h] > out_cap) { rc = fail(ctx, ATSC_E_CAPACITY, "decompress_frames: out_cap"); goto done; }
         HCHK(pool_alloc(ctx, (void **)&d_o[h], std::max<uint64_t>(n[h], 1) * sizeof(double)));
@@ -2173,7 +2223,8 @@ static int decompress_frames_halves(atsc_ctx *ctx, const uint8_t *body, uint64_t
     }
     HCHK(hipStreamSynchronize(ds));
     HCHK(hipStreamSynchronize(ws));
-    for (int h = 0; h < used; ++h) {
+    for (int h = 0; h < NP; ++h) {
+        if (!dp[h]) continue;
         int status = 0;
         if (h_status) status = h_status[h];
         else HCHK(hipMemcpy(&status, dp[h]->d_status, sizeof(int), hipMemcpyDeviceToHost));
@@ -2185,6 +2236,7 @@ done:
     if (rc) {
         (void)hipStreamSynchronize(ws);
         (void)hipStreamSynchronize(ds);
+        *out_n = 0;  // (the caller's buffer may hold the first parts' samples: they are not a result)
     }
     for (int h = 0; h < MAXP; ++h) {
         pool_free(ctx, d_o[h]);
@@ -2299,7 +2351,9 @@ extern "C" int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64
 {
     ATSC_API_BEGIN
     if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames: null argument");
-    return decompress_frames_impl(ctx, body, body_len, has_count, out, out_cap, nullptr, out_n);
+    const int rc = decompress_frames_impl(ctx, body, body_len, has_count, out, out_cap, nullptr, out_n);
+    if (rc) *out_n = 0;  // whatever `out` holds by now is not a result
+    return rc;
     ATSC_API_END
 }
 extern "C" int atsc_decompress_frames_alloc(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len,
@@ -2308,6 +2362,8 @@ extern "C" int atsc_decompress_frames_alloc(atsc_ctx *ctx, const uint8_t *body, 
     ATSC_API_BEGIN
     if (!ctx || !body || !out || !out_n) return fail(ctx, ATSC_E_INVALID, "decompress_frames_alloc: null argument");
     *out = nullptr;
-    return decompress_frames_impl(ctx, body, body_len, has_count, nullptr, 0, out, out_n);
+    const int rc = decompress_frames_impl(ctx, body, body_len, has_count, nullptr, 0, out, out_n);
+    if (rc) *out_n = 0;
+    return rc;
     ATSC_API_END
 }

@@ -236,7 +236,8 @@ int atsc_decompress_plan_dev(atsc_ctx *ctx, const atsc_dplan *dp, const uint8_t 
                              double *d_out, void *stream);
 /* Host-pointer convenience (synchronous). out_n receives the sample count.  On an error `out` may hold
  * samples of the frames in front of the failing record (a destination registered with atsc_host_register
- * is filled part by part while the later records are still being parsed); out_n is not written then. */
+ * is filled part by part while the later records are still being parsed; a pageable one is only written
+ * once every payload has decoded): *out_n = 0 then, so that nothing in `out` can be mistaken for a result. */
 int atsc_decompress_frames(atsc_ctx *ctx, const uint8_t *body, uint64_t body_len, int has_count,
                            double *out, uint64_t out_cap, uint64_t *out_n);
 /* The same with the output allocated by the library at exactly the decoded length (atsc_free):

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 ME5 = float(np.float32(5) / np.float32(100))
 ME1 = float(np.float32(1) / np.float32(100))
+ME3 = float(np.float32(3) / np.float32(100))
 
 
 @pytest.fixture(scope="module")
@@ -469,6 +470,177 @@ def test_auto_large_frames(ctx, A, oracle, sizes, klasses):
     _log(P.assert_summary(s, len(offs) - 1, "large frames %s classes %s codecs %s" % (sizes, klasses, s["codecs"])))
 
 
+@pytest.mark.parametrize("me", [ME1, 0.0, ME3], ids=["e1", "e0", "e3"])
+@pytest.mark.parametrize("sizes,klasses", [
+    ([8192, 16384, 32768, 65536], (0, 1, 2, 3, 4)),     # the grid path's lengths, every class
+    ([131072], (0, 1, 2, 3)),                            # configs[3]'s frame in the CLI's framing
+    ([5000, 6500, 20000, 4097], (0, 1, 3)),              # no 243 x 9 P split: the general kernels
+], ids=["pow2", "131072", "other"])
+def test_auto_large_frames_error_bounds(ctx, A, oracle, sizes, klasses, me):
+    """The auto selector on large frames at the error bounds round 3 never held against the oracle's ENCODER:
+    e = 1 % (configs[3]: FFT ladders that go on past their first trip, polynomial trips woven in between,
+    `poly_next_lb` pruning), e = 0 (every ladder runs to its end; Noop is never a candidate, so the selector's pick
+    among failing candidates -- frame/mod.rs:113-147 -- is what is compared) and e = 3 %."""
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in klasses:
+            xs.append(H.synth_series(1700 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    s = P.compare_batch(oracle, ctx, x, np.array(offs, dtype=np.uint64), A.AUTO, True, me)
+    _log(P.assert_summary(s, len(offs) - 1, "large frames %s classes %s me %.3f codecs %s" % (sizes, klasses, me, s["codecs"])))
+
+
+def test_config3_in_chunker_framing_against_the_oracle(ctx, A, oracle):
+    """BASELINE.json configs[3] as the `atsc` CLI frames it: series of 262144 samples, class = series % 5, each cut
+    into two 131072-sample frames (optimizer/mod.rs:78-98), --compressor auto, e = 1 %.  Twelve series = 24 frames,
+    every one against the oracle's encoder (codec, K, bin order, coefficients, reported error); then the stream is
+    decoded on the GPU and held against the oracle's decode of the same bytes."""
+    NS, PER, F = 12, 262144, 131072
+    x = np.concatenate([H.synth_series(s, PER, klass=s % 5) for s in range(NS)])
+    sizes = []
+    for s in range(NS):
+        sizes += A.chunk_sizes(PER)
+    assert sizes == [F] * (2 * NS)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME1)
+    _log(P.assert_summary(s, 2 * NS, "configs[3] chunker framing, e = 1 %%, codecs %s" % s["codecs"]))
+    assert len(s["codecs"]) >= 3
+    out = ctx.decompress_host(s["records"])
+    ref = oracle.decompress_data(A.bro_prefix(2 * NS) + s["records"])
+    for i in range(2 * NS):
+        seg = slice(i * F, (i + 1) * F)
+        if s["chosen"][i] == oracle.FFT:
+            scale = max(np.max(np.abs(ref[seg])), 1e-30)
+            tol = (4 + np.log2(F)) * scale * 2.0 ** -23 + 1.00001e-5
+            assert np.max(np.abs(out[seg] - ref[seg])) <= tol, i
+        else:
+            assert np.array_equal(out[seg], ref[seg]), (i, s["chosen"][i])
+        if s["chosen"][i] in (oracle.CONSTANT, oracle.RLE):
+            assert np.array_equal(out[seg], x[seg]), i
+
+
+def _config3_device_series(torch, dev, n_series, per):
+    """configs[3] on the device: series s has class s % 5; classes 0-2 are generated by torch on the
+    GPU, the gauge and constant classes on the host."""
+    d_x = torch.empty(n_series * per, dtype=torch.float64, device=dev)
+    for s in range(n_series):
+        d_x[s * per:(s + 1) * per] = H.synth_series_torch(torch, dev, s, per, s % 5)
+    return d_x
+
+
+@pytest.mark.parametrize("framing", ["f256", "chunker"])
+def test_full_size_config3_config4_one_gpu(ctx, A, framing):
+    """BASELINE.json configs[3] and configs[4] at FULL size on one GPU: 4096 series x 262144 samples = 2^30 samples
+    (8.6 GB of f64), auto, e = 1 %, once in 256-sample frames (bench.py's framing: 4 194 304 frames) and once in the
+    reference chunker's 131072-sample frames (8192 frames); then the whole stream is decoded (configs[4]).  No oracle
+    at this size: determinism, record offsets, the codec mix, bit-exact round trip of the lossless codecs, every lossy
+    frame within the bound the selector applied, decoded error against the reported one.  Everything stays on the
+    device except the record bytes the decode plan is built from."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    NS, PER = 4096, 262144
+    n = NS * PER
+    F = 256 if framing == "f256" else 131072
+    L_over_n = 288.0 / 256.0 if F == 256 else 139968.0 / 131072.0
+    d_x = _config3_device_series(torch, dev, NS, PER)
+    off = np.arange(0, n + 1, F, dtype=np.uint64)
+    nf = len(off) - 1
+    plan = ctx.plan(off)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = plan.alloc_outputs(torch, dev)
+    plan.compress(d_x, outs, A.AUTO, True, ME1, 0, st)
+    torch.cuda.synchronize()
+    rec_off = outs["rec_off"]
+    total = int(rec_off[-1].item())
+    assert total <= plan.body_bound
+    assert bool((rec_off[1:] > rec_off[:-1]).all())
+    body1 = outs["body"][:total].clone()
+    chosen = outs["chosen"].clone()
+    err = outs["err"].clone()
+    plan.compress(d_x, outs, A.AUTO, True, ME1, 0, st)  # determinism
+    torch.cuda.synchronize()
+    assert int(outs["rec_off"][-1].item()) == total and torch.equal(outs["body"][:total], body1)
+    assert torch.equal(outs["chosen"], chosen)
+    del outs
+    plan.close()
+    # a series' class decides its codec family: constant series -> Constant, the gauge -> RLE (or a lossy codec that
+    # is smaller within 1 %), the others lossy
+    ch = chosen.reshape(NS, nf // NS)
+    cls = torch.arange(NS, device=dev) % 5
+    assert bool((ch[cls == 4] == A.CONSTANT).all())
+    assert not bool((ch[cls <= 2] == A.CONSTANT).any())  # (a 256-sample frame of the gauge may sit inside equal runs)
+    assert bool(((ch[cls == 3] == A.CONSTANT) | (ch[cls == 3] == A.RLE)).float().mean() > 0.9)
+    assert not bool((chosen == A.NOOP).any())
+    # configs[4]: decode the whole stream
+    body = body1.cpu().numpy()
+    dp = A.DPlan(ctx, body)
+    assert dp.n_frames == nf and dp.n_samples == n
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    dp.decompress(body1, d_out, st)
+    torch.cuda.synchronize()
+    dp.close()
+    xo = d_x.reshape(nf, F)
+    oo = d_out.reshape(nf, F)
+    lossless = (chosen == A.CONSTANT) | (chosen == A.RLE)
+    assert bool((oo[lossless] == xo[lossless]).all())
+    assert bool((err[lossless] == 0).all())
+    lossy = ~lossless
+    assert bool((err[lossy] <= ME1).all())
+    fm = ((oo - xo).abs() / xo.abs()).sum(dim=1) / float(F)  # (no zero samples in these classes)
+    poly = chosen == A.POLYNOMIAL
+    assert bool(((fm[poly] - err[poly]).abs() <= 1e-9).all())
+    fft = chosen == A.FFT
+    # the reported error is the mean over the L Gibbs-padded samples (fft.rs:345): over the n real samples the sum
+    # can only be smaller, the divisor is n instead of L
+    assert bool((fm[fft] <= ME1 * L_over_n + 2e-6).all())
+    codecs = {int(c): int((chosen == c).sum().item()) for c in torch.unique(chosen).tolist()}
+    _log("configs[3]/[4] full size on one GPU, %s framing: %d frames, ratio %.3f, codecs %s, worst lossy MAPE %.5f"
+         % (framing, nf, 8.0 * n / (total + 12), codecs, float(fm[lossy].max().item())))
+    del d_x, d_out, xo, oo
+
+
+def test_decode_in_parts_with_records_longer_than_a_part(ctx, A):
+    """atsc_decompress_frames into registered memory walks the records in parts; a record longer than a part's stride
+    (131072-sample Noop / RLE frames: ~0.2-1.2 MB each) ends behind the next part's limit, and that part is then
+    empty -- not an error.  Same samples as the pageable (one-plan) path."""
+    import ctypes as C
+
+    from atsc_amd import capi
+
+    lib = capi.lib()
+    F = 131072
+    for comp, klass, nfr in ((A.NOOP, 0, 3), (A.RLE, 3, 5), (A.FFT, 1, 4)):
+        x = np.concatenate([H.synth_series(60 + k, F, klass=klass) for k in range(nfr)])
+        off = H.frame_offsets(len(x), F)
+        rec, _, _, _ = ctx.compress_host(x, off, comp, comp == A.FFT, 0.0, 0)
+        if len(rec) < (1 << 20):
+            # (the parts form starts at 1 MB of records: pad the stream with more frames of the same kind)
+            reps = (1 << 20) // len(rec) + 1
+            x = np.tile(x, reps)
+            off = H.frame_offsets(len(x), F)
+            rec, _, _, _ = ctx.compress_host(x, off, comp, comp == A.FFT, 0.0, 0)
+        assert len(rec) >= (1 << 20)
+        ref = ctx.decompress_host(rec)  # pageable destination: one plan
+        dec = np.full(len(x), -1.0)
+        recarr = np.frombuffer(rec, dtype=np.uint8).copy()
+        done = []
+        try:
+            for a in (dec, recarr):
+                capi.check(lib.atsc_host_register(C.c_void_p(a.ctypes.data), a.nbytes), ctx._h)
+                done.append(a)
+            on = C.c_uint64()
+            rc = lib.atsc_decompress_frames(ctx._h, recarr.ctypes.data_as(C.POINTER(C.c_uint8)), len(rec), 0,
+                                            dec.ctypes.data_as(C.POINTER(C.c_double)), len(dec), C.byref(on))
+            capi.check(rc, ctx._h)
+            assert on.value == len(x)
+            assert np.array_equal(dec, ref), comp
+        finally:
+            for a in done:
+                lib.atsc_host_unregister(C.c_void_p(a.ctypes.data))
+
+
 def test_host_calls_on_registered_memory_and_after_a_trim(ctx, A):
     """atsc_host_register page-locks the caller's buffers: atsc_compress_frames then uploads by DMA and copies the
     records back part by part beside the later uploads, atsc_decompress_frames enqueues the records' copy before the
@@ -565,7 +737,7 @@ def test_decode_in_parts_reports_a_bad_record_in_a_later_part(ctx, A):
                 rc, onv = call(len(rec0))
             else:
                 rc, onv = call(len(rec0) - 3)  # the last record is cut short
-            assert rc != 0 and onv == 12345, (mutate, rc, onv)
+            assert rc != 0 and onv == 0, (mutate, rc, onv)  # (no result: *out_n = 0 even when parts were copied)
             recarr[:] = saved
             dec[:] = -1.0
             rc, onv = call(len(rec0))
@@ -613,7 +785,8 @@ def test_forced_fft_large_frames_with_folded_positions(ctx, A, oracle):
     _log(P.assert_summary(s, 3, "forced FFT, 131072-sample frames with folded positions (%d duplicates)" % dup))
 
 
-def test_reference_chunker_long_series(ctx, A, oracle):
+@pytest.mark.parametrize("me", [ME5, ME1, 0.0, ME3], ids=["e5", "e1", "e0", "e3"])
+def test_reference_chunker_long_series(ctx, A, oracle, me):
     """compress_data flow (main.rs:130-165) on a 300000-sample series: 131072, 131072, 32768,
     4096, 512, 480 -- every kernel tier in one batch, byte-compared at the stream level."""
     x = H.synth_series(42, 300000, block=50000)
@@ -621,8 +794,8 @@ def test_reference_chunker_long_series(ctx, A, oracle):
     sizes = A.chunk_sizes(len(x))
     assert sizes == [131072, 131072, 32768, 4096, 512, 480]
     off = np.cumsum([0] + sizes).astype(np.uint64)
-    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, ME5)
-    _log(P.assert_summary(s, len(sizes), "chunker long series codecs %s" % s["codecs"]))
+    s = P.compare_batch(oracle, ctx, x, off, A.AUTO, True, me)
+    _log(P.assert_summary(s, len(sizes), "chunker long series me %.3f codecs %s" % (me, s["codecs"])))
 
 
 def test_decompress_large_frames(ctx, A, oracle):
@@ -796,6 +969,55 @@ def test_pipelined_batches_match_plain_calls(ctx, A):
         assert np.array_equal(got[1], ref[b][1]) and np.array_equal(got[2], ref[b][2])
         assert np.array_equal(got[3], ref[b][3], equal_nan=True)
     plan.close() if hasattr(plan, "close") else None
+
+
+_FAIL_SET_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import atsc_amd
+from tests import helpers as H
+me = float(np.float32(5) / np.float32(100))
+ctx = atsc_amd.Context(0)
+ctx.set_chains(4)
+dev = torch.device("cuda:0")
+for F, nf in ((256, 2048), (131072, 6)):
+    xs = [H.synth_series(300 + b, F * nf, block=F * max(nf // 6, 1), class_shift=b) for b in range(3)]
+    d_xs = [torch.from_numpy(v).to(dev) for v in xs]
+    off = H.frame_offsets(F * nf, F)
+    plan = ctx.plan(off)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = []
+    o = plan.alloc_outputs(torch, dev)
+    for b in range(3):
+        plan.compress(d_xs[b], o, atsc_amd.AUTO, True, me, 0, st)
+        torch.cuda.synchronize()
+        t = int(o["rec_off"][-1].item())
+        ref.append(o["body"][:t].cpu().numpy().tobytes())
+    outs = [plan.alloc_outputs(torch, dev) for _ in range(8)]
+    for i in range(24):
+        plan.compress(d_xs[i % 3], outs[i % 8], atsc_amd.AUTO, True, me, 0, st, pipelined=True)
+    plan.join(st)
+    torch.cuda.synchronize()
+    for i in range(16, 24):
+        t = int(outs[i % 8]["rec_off"][-1].item())
+        assert outs[i % 8]["body"][:t].cpu().numpy().tobytes() == ref[i % 3], (F, i)
+    plan.close()
+print("FAILSET-OK")
+"""
+
+
+@pytest.mark.parametrize("fail_from", [1, 2, 3, 5])
+def test_pipelined_calls_fall_back_to_fewer_chains_when_a_scratch_set_does_not_fit(fail_from):
+    """The first pipelined call builds two scratch sets per chain.  When set q cannot be allocated (ATSC_DEBUG_FAIL_SET=q
+    lets its third block fail, as an out-of-memory would) the blocks it did get go back to the pool and the plan goes on
+    with the sets it has: q = 1 -> one set, every call behind its predecessor; q = 2, 3 -> one chain; q = 5 -> two.
+    The records are those of plain calls either way."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ATSC_DEBUG_FAIL_SET=str(fail_from), GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _FAIL_SET_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILSET-OK" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
 
 
 @pytest.mark.parametrize("F,nf,chains", [(131072, 12, 2), (256, 4096, 4), (131072, 12, 1)])
