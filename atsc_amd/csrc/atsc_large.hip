@@ -339,7 +339,7 @@ DEVI float2 *fft_large(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw,
 // workspace carve (bytes) -- the host uses the same function to size a slot
 __host__ __device__ inline uint64_t lw_align(uint64_t v) { return (v + 255) & ~255ull; }
 struct LargeWs {
-    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, o_part, o_tst, bytes;
+    uint64_t o_a, o_b, o_c, o_x, o_nb, o_sel, o_mm, o_aux, o_rec, o_hp, o_tab, o_rps, o_rph, o_spos, o_cnt, o_front, o_part, o_tst, o_rbm, bytes;
 };
 __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint32_t kcap)
 {
@@ -365,6 +365,7 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.o_part = o; o += lw_align(4096);                // first polynomial trip: MAPE sums of the 4096-sample chunks (k_large_poly1);
                                                       // fast path: [512] sums and [1536] run counts of the 1024-sample pieces
     w.o_tst = o; o += lw_align(32 * 32);              // k_large_cols243: statistics of each column tile (TileStats)
+    w.o_rbm = o; o += lw_align(n / 8 + 64);           // fast path: one bit per sample, set where a run starts (poly1_piece)
     w.bytes = o;
     return w;
 }

@@ -367,8 +367,13 @@ DEVI void poly1_piece(const double *xs, const DevPlan &P, unsigned char *ws, con
 #pragma unroll
         for (uint32_t u = 0; u < SPB4; ++u) {
             const uint32_t i = b0 + u * RT + tid;
+            // where the runs start, one bit per sample (rle.rs:142-189; read by k_large_decide1 when RLE can win): a
+            // wavefront's 64 samples are consecutive and start at a multiple of 64 -- its ballot is one word of the map
+            const bool rstart = i < c1 && (i == 0 || g[u] != pv[u]);
+            const unsigned long long rmask = __ballot(rstart);
+            if ((tid & 63u) == 0 && i < c1) ((unsigned long long *)(ws + lay.o_rbm))[i >> 6] = rmask;
             if (i >= c1) continue;
-            if (i == 0 || g[u] != pv[u]) { ++runs; ib += vlen(i); }
+            if (rstart) { ++runs; ib += vlen(i); }
             double sv;
             if (i == n - 1) {
                 sv = g[u];

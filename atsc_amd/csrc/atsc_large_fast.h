@@ -27,6 +27,8 @@ constexpr uint32_t FAST_K_MAX = 1344;      // K1 <= mf = n / 100 = 1310
 constexpr uint32_t FAST_OWN = 4608;        // positions below bins - 65536 = 4449 can collide after `pos as u16`
 constexpr uint32_t FAST_LIST_OFF = 0;        // inside buffer B: the list, then the bucket bounds, then the sort keys
 constexpr uint32_t FAST_PARTIAL_OFF = 8192;  // inside buffer C (as TRIP_PARTIAL_OFF)
+constexpr uint32_t FAST_RLE_ENC_MAX = 3072;  // runs k_large_decide1 sorts and sizes in LDS (index bytes < 2^16, groups < 2^16)
+constexpr uint32_t FAST_RLE_DEC_MAX = 6144;  // runs of an RLE frame k_large_dparse sorts in LDS (as RLE_LDS_RUNS)
 
 // Geometry of a frame this path serves: M = 243 x md, md = 9 P, P = 2^lg = 2 .. 32 (8192 .. 131072 samples); ceil(md / 16)
 // tiles of 16 output columns; where the bucket bounds and the payload-order keys sit behind the list in buffer B (the
@@ -403,7 +405,118 @@ __device__ __forceinline__ void large_decide1(
     const uint32_t Z = bins - zero_bins;
     const uint32_t K1 = min(P.mf, Z);
     if (K1 < 8) { FAST_WHY(6); return; }
-    if (!can_win(1 + vlen(K1) + 9 * K1 + 8, 0)) {
+    const uint32_t fft1_size = 1 + vlen(K1) + 9 * K1 + 8;  // the least the FFT candidate can store
+
+    // ---- RLE, exactly (rle.rs:142-189), when its bound can still win and the runs fit the LDS ----
+    // The run starts come as a bit map from the polynomial pieces (poly1_piece); the runs are sorted by (value bits,
+    // start) = the reference's BTreeMap order and sized.  RLE reports error 0.0 and so passes whenever 0.0 <= max_error
+    // (the fast path's condition).  When its payload beats the least either ladder can still store the frame is decided
+    // here: no norm is selected, no transform evaluated -- a gauge's 131072-sample frame used to wait for the general
+    // kernel (156 us for six of them).  Otherwise nothing changes: the exact size is not offered.
+    {
+        const uint32_t lds64 = cv.own_n + 2 * cv.k_max + cv.cand_max;       // u64 entries from own[] on
+        const uint32_t rcap = min(FAST_RLE_ENC_MAX, (8u * lds64) / 28u);     // 28 bytes of LDS per run
+        if (prm.tile_stats && rle_R >= 1 && rle_R <= rcap && can_win(rle_lb, 2) && rle_lb < fft1_size &&
+            (poly_final || rle_lb < poly2_lb)) {
+            const uint32_t R = rle_R;
+            unsigned long long *kk = own;                 // value bits of run i
+            uint32_t *pp = (uint32_t *)(kk + rcap);       // run index in start order (the sort's tie-break)
+            uint32_t *rst = pp + rcap;                    // start of run i (start order)
+            uint32_t *aux = rst + rcap;                   // heads / scans
+            uint32_t *hp = aux + rcap;                    // first sorted run of group g (hp[D] = R): rcap + 1 <= rcap + 8
+            uint32_t *rph = h2;                           // header bytes of group g (2048 + 2048 words: h2, dcnt)
+            const unsigned long long *bm = (const unsigned long long *)(ws + lay.o_rbm);
+            const uint32_t nw = n >> 6;                   // 64-sample words (n is a multiple of 64 on this path)
+            // starts in order: every thread expands the words tid, tid + LT, ... -- counts first, a scan over the
+            // threads' word slices would reorder them, so the words are taken in contiguous slices of wpt per thread
+            const uint32_t wpt = (nw + LT - 1) / LT;
+            uint32_t cnt = 0;
+            for (uint32_t w = tid * wpt; w < min(nw, (tid + 1) * wpt); ++w) cnt += (uint32_t)__popcll(bm[w]);
+            dcnt[tid] = cnt;
+            __syncthreads();
+            const uint32_t total = block_excl_scan<LW>(dcnt, LT, wsum);
+            if (total != R) { FAST_WHY(15); return; }  // (cannot happen: the pieces counted the same bits)
+            {
+                uint32_t o = dcnt[tid];
+                for (uint32_t w = tid * wpt; w < min(nw, (tid + 1) * wpt); ++w) {
+                    unsigned long long m = bm[w];
+                    while (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        rst[o++] = 64u * w + b;
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < R; i += LT) {
+                kk[i] = (unsigned long long)__double_as_longlong(xs[rst[i]]);
+                pp[i] = i;
+            }
+            __syncthreads();
+            uint32_t p2 = 1;
+            while (p2 < R) p2 <<= 1;
+            block_sort<LW, false>((uint64_t *)kk, pp, R, p2);
+            for (uint32_t i = tid; i < R; i += LT) aux[i] = (i == 0 || kk[i] != kk[i - 1]) ? 1u : 0u;
+            __syncthreads();
+            const uint32_t D = block_excl_scan<LW>(aux, R, wsum);
+            if (D <= 4096) {
+                for (uint32_t i = tid; i < R; i += LT)
+                    if (i == 0 || kk[i] != kk[i - 1]) hp[aux[i]] = i;
+                if (tid == 0) hp[D] = R;
+                __syncthreads();
+                uint32_t hb = 0;
+                for (uint32_t gi = tid; gi < D; gi += LT) {
+                    const uint32_t b = value_bytes(bitdepth, __longlong_as_double((long long)kk[hp[gi]])) + vlen(hp[gi + 1] - hp[gi]);
+                    rph[gi] = b;
+                    hb += b;
+                }
+                {
+                    int parity = 0;
+                    hb = block_sum_u32<LW>(hb, (double *)(smem + 256), parity);
+                }
+                const uint32_t rle_size = 2 + vlen(D) + hb + rle_ib;
+                // frame/mod.rs:113-147: the smallest passing payload, the first of [FFT, Polynomial, RLE] on ties
+                const bool beats_poly = can_win(rle_size, 2) && (poly_final || rle_size < poly2_lb);
+                if (beats_poly && rle_size < fft1_size) {
+                    // emit (rle.rs:40-67): per group its value and run count, then the starts of its runs
+                    const uint32_t hdr = 2 + vlen(D);
+                    // one scan for both prefixes: (group heads before i) << 16 | index varint bytes before i
+                    for (uint32_t i = tid; i < R; i += LT) {
+                        const bool head = (i == 0 || kk[i] != kk[i - 1]);
+                        aux[i] = (head ? 0x10000u : 0u) | vlen(rst[pp[i]]);
+                    }
+                    __syncthreads();
+                    (void)block_excl_scan<LW>(aux, R, wsum);
+                    const uint32_t hbt = block_excl_scan<LW>(rph, D, wsum);
+                    for (uint32_t i = tid; i < R; i += LT) {
+                        const uint32_t st = rst[pp[i]];
+                        const bool head = (i == 0 || kk[i] != kk[i - 1]);
+                        const uint32_t pk = aux[i], ps = pk & 0xffffu;
+                        const uint32_t gi = head ? (pk >> 16) : (pk >> 16) - 1;
+                        const uint32_t ghb = (gi + 1 < D ? rph[gi + 1] : hbt);  // header bytes up to and incl. group gi
+                        if (head) {
+                            uint8_t *q = out + hdr + rph[gi] + ps;
+                            q += put_value(q, bitdepth, __longlong_as_double((long long)kk[i]));
+                            put_varint(q, hp[gi + 1] - hp[gi]);
+                        }
+                        put_varint(out + hdr + ghb + ps, st);
+                    }
+                    if (tid == 0) {
+                        out[0] = 60;
+                        out[1] = (uint8_t)bitdepth;
+                        put_varint(out + 2, D);
+                        res[fid].err = 0.0;
+                        res[fid].len = rle_size;
+                        res[fid].chosen = ATSC_RLE;
+                        fs->status = 2;
+                    }
+                    return;
+                }
+            }
+            __syncthreads();  // (own[] .. cand[] and h2 / dcnt are reused below)
+        }
+    }
+    if (!can_win(fft1_size, 0)) {
         // even the first trip's payload loses to the polynomial, which passes: no transform is evaluated at all
         if (!(poly_final && pcur <= me) || can_win(rle_lb, 2)) { FAST_WHY(7); return; }
         fast_emit_poly(out, res[fid], xs, n, bitdepth, pK, pstep, smin, smax, pcur, h2, wsum);
@@ -707,6 +820,45 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     const FastState *fs = (const FastState *)(ws + lay.o_front);
     if (fast_geo(P).lg != (uint32_t)LG) return;
     if constexpr (DECODE) {
+        if (fs->status == 4) {
+            // An RLE frame k_large_dparse prepared: this workgroup writes piece blockIdx.x of the frame.  A wavefront takes
+            // 64 runs at a time, one per lane (start, next start, value), and writes them one after the other, 64 samples a
+            // store; samples in front of the first run are 0.0 (rle.rs:204-236).
+            const uint32_t n = P.n, E = fs->K1;
+            const uint32_t pieces = fast_geo(P).tiles;
+            if (blockIdx.x >= pieces) return;
+            const uint32_t *rstart = (const uint32_t *)(ws + lay.o_hp);
+            const double *rval = (const double *)(ws + lay.o_rec);
+            const uint32_t *ptab = (const uint32_t *)(ws + lay.o_part);
+            double *out = frame_out(outp, fr);
+            const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / pieces);
+            const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / pieces);
+            const uint32_t c0 = ptab[blockIdx.x], c1 = ptab[blockIdx.x + 1];  // runs that start at or before i0 / i1
+            const uint32_t lane = tid & 63u, wv = tid >> 6;
+            if (c0 == 0) {
+                const uint32_t z1 = min(i1, rstart[0]);
+                for (uint32_t j = i0 + tid; j < z1; j += CT) out[j] = 0.0;
+            }
+            const uint32_t a = c0 ? c0 - 1 : 0;
+            for (uint32_t base = a + 64u * wv; base < c1; base += 64u * (CT / 64)) {
+                const uint32_t r = base + lane;
+                uint32_t st = 0, en = 0;
+                double v = 0.0;
+                if (r < c1) {
+                    st = rstart[r];
+                    en = (r + 1 < E) ? rstart[r + 1] : n;
+                    v = rval[r];
+                }
+                const uint32_t cc = min(64u, c1 - base);
+                for (uint32_t u = 0; u < cc; ++u) {
+                    const uint32_t s0 = max((uint32_t)__builtin_amdgcn_readlane((int)st, (int)u), i0);
+                    const uint32_t e0 = min((uint32_t)__builtin_amdgcn_readlane((int)en, (int)u), i1);
+                    const double vv = lane_f64(v, (int)u);
+                    for (uint32_t j = s0 + lane; j < e0; j += 64) out[j] = vv;
+                }
+            }
+            return;
+        }
         if (fs->status == 3) {
             // A polynomial frame k_large_dparse prepared: this workgroup evaluates piece blockIdx.x of the frame's tiles
             // (polynomial.rs:342-373 with the encoder's tables -- tangents per segment, Hermite basis per in-segment
@@ -1084,7 +1236,7 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
     const FastGeo geo = fast_geo(P);
-    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL) || !geo.ok || (P.pre & 1u) || (fr.n & 1u)) return;
+    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL && fr.tag != ATSC_RLE) || !geo.ok || (P.pre & 1u) || (fr.n & 1u)) return;
     // LDS: [hdr 512][payload window STG_BYTES][tab 1024 u32][pos FAST_K_MAX u32 + dead FAST_K_MAX u32][zl][zs]
     uint32_t *bc = (uint32_t *)smem;
     float *bcf = (float *)(smem + 64);
@@ -1116,6 +1268,125 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     // (next^64), a single thread hops from group to group of 64 entries, and the sixteen wavefronts parse the
     // groups side by side.
     uint8_t *win = smem + 512 + mis;
+    if (fr.tag == ATSC_RLE) {
+        // RLE frame (rle.rs:204-236): groups of (value, count, count run starts).  One wavefront walks the group headers
+        // (below), every thread decodes starts, and the keys (start << 32 | group) are sorted in LDS (runs that share a
+        // start: sorted by (start, group), all but the last of them are empty -- the reference's outcome); then (start,
+        // value) per run in sample order and, per piece of the tile grid, how many runs start at or before the piece's
+        // first sample go to the workspace.  k_large_trip243<true> expands the runs, one piece per workgroup.
+        unsigned long long *lk = (unsigned long long *)zl;  // zl + zs: 64512 bytes
+        double *gvals = (double *)(ws + lay.o_tab);
+        // Group table (tab .. ldead: 14336 bytes): per group {offset of its first start, 1-byte starts, 3-byte starts,
+        // runs before the group}.  The encoder pushes a group's starts in scan order (rle.rs:158-169), so their varint
+        // widths only grow -- 1 byte below 251, then 3 (marker 251), then 5 (marker 252) -- and the walker finds a
+        // group's end from two marker scans, 64 bytes / entries a step, instead of decoding one varint after the other
+        // (a lone wavefront pays ~700 cycles of LDS latency per dependent field: 327 us for a gauge's 964 runs).  The
+        // starts are then decoded by every thread at once, and each checks its marker: a stream that is not built that
+        // way is left to the general decoder.
+        constexpr uint32_t GMAX = 896;
+        uint4 *gtab = (uint4 *)tab;
+        if (tid < 64) {
+            const uint32_t lane = tid;
+            RdS r{pay, fr.payload_len, 0, false, win, 0, fr.payload_len, STG_BYTES};
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            const uint64_t groups = rds_varint(r);
+            bool bad = r.bad || bd > 3 || groups == 0 || groups > GMAX;
+            uint32_t e = 0;
+            for (uint32_t gi = 0; gi < (uint32_t)groups && !bad; ++gi) {
+                const double v = rds_value(r, bd);
+                const uint64_t c64 = rds_varint(r);
+                if (r.bad || c64 == 0 || c64 > FAST_RLE_DEC_MAX - e) { bad = true; break; }
+                const uint32_t c = (uint32_t)c64, o = r.pos;
+                if (lane == 0) gvals[gi] = v;
+                // leading 1-byte starts, then 3-byte ones; what is left must be 5-byte starts
+                uint32_t a = 0, b = 0;
+                for (;;) {
+                    const uint32_t k = a + lane;
+                    const bool one = k < c && o + k < r.len && win[o + k] < 251;
+                    const unsigned long long m = __ballot(!one);
+                    if (m) { a += (uint32_t)__builtin_ctzll(m); break; }
+                    a += 64;
+                }
+                a = min(a, c);
+                for (;;) {
+                    const uint32_t k = b + lane;
+                    const bool three = a + k < c && o + a + 3 * k + 2 < r.len && win[o + a + 3 * k] == 251;
+                    const unsigned long long m = __ballot(!three);
+                    if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
+                    b += 64;
+                }
+                b = min(b, c - a);
+                const uint32_t bytes = a + 3 * b + 5 * (c - a - b);
+                if (o + bytes > r.len) { bad = true; break; }
+                if (lane == 0) gtab[gi] = make_uint4(o, a, b, e);
+                r.pos = o + bytes;
+                e += c;
+            }
+            if (r.pos != r.len) bad = true;  // (anything unusual is the general decoder's to judge)
+            if (tid == 0) { bc[0] = bad ? 0u : 1u; bc[1] = e; bc[2] = (uint32_t)groups; bc[3] = 0; }
+        }
+        __syncthreads();
+        if (!bc[0] || bc[1] == 0) return;
+        {
+            const uint32_t E0 = bc[1], D = bc[2];
+            for (uint32_t j = tid; j < E0; j += LT) {
+                uint32_t lo = 0, hi = D;  // the last group that starts at or before run j
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (gtab[mid].w <= j) lo = mid;
+                    else hi = mid;
+                }
+                const uint4 g = gtab[lo];
+                const uint32_t k = j - g.w;
+                uint32_t idx, okk;
+                if (k < g.y) {
+                    idx = win[g.x + k];
+                    okk = idx < 251 ? 1u : 0u;
+                } else if (k < g.y + g.z) {
+                    const uint32_t q = g.x + g.y + 3 * (k - g.y);
+                    idx = (uint32_t)win[q + 1] | ((uint32_t)win[q + 2] << 8);
+                    okk = win[q] == 251 ? 1u : 0u;
+                } else {
+                    const uint32_t q = g.x + g.y + 3 * g.z + 5 * (k - g.y - g.z);
+                    idx = (uint32_t)win[q + 1] | ((uint32_t)win[q + 2] << 8) | ((uint32_t)win[q + 3] << 16) | ((uint32_t)win[q + 4] << 24);
+                    okk = win[q] == 252 ? 1u : 0u;
+                }
+                if (!okk || idx >= fr.n) bc[3] = 1;
+                lk[j] = ((unsigned long long)idx << 32) | lo;
+            }
+        }
+        __syncthreads();
+        if (bc[3]) return;
+        const uint32_t E = bc[1];
+        uint32_t p2 = 1;
+        while (p2 < E) p2 <<= 1;
+        block_sort<LW, true>((uint64_t *)lk, nullptr, E, p2);
+        uint32_t *rstart = (uint32_t *)(ws + lay.o_hp);
+        double *rval = (double *)(ws + lay.o_rec);
+        for (uint32_t i = tid; i < E; i += LT) {
+            const unsigned long long k = lk[i];
+            rstart[i] = (uint32_t)(k >> 32);
+            rval[i] = gvals[(uint32_t)(k & 0xffffffffull)];
+        }
+        uint32_t *ptab = (uint32_t *)(ws + lay.o_part);
+        if (tid <= geo.tiles) {
+            uint32_t cnt = E;
+            if (tid < geo.tiles) {
+                const uint32_t i0 = (uint32_t)(((uint64_t)fr.n * tid) / geo.tiles);
+                uint32_t lo = 0, hi = E;  // runs with start <= i0
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)(lk[mid] >> 32) <= i0) lo = mid + 1;
+                    else hi = mid;
+                }
+                cnt = lo;
+            }
+            ptab[tid] = cnt;
+        }
+        if (tid == 0) { fs->K1 = E; fs->status = 4; }
+        return;
+    }
     if (fr.tag == ATSC_POLYNOMIAL) {
         // Catmull-Rom frame (polynomial.rs:395-404): the points into the workspace as doubles, the rest is
         // k_large_trip243<true>'s (one piece of the frame per workgroup).  Fixed-width points (F64 / U8) are read by

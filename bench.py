@@ -224,6 +224,27 @@ def end_to_end(ctx, atsc_amd, x, off, me, reps=5):
     return out
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch / per call from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE doubled per
+    the gfx950 rule + WRITE_SIZE, collected by separate rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes -- the
+    counters cannot be read inside this run).  -> (bytes or None, source)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = d[key]
+        return float(e["bytes"]), "profiles/%s (%s)" % (e["file"], d.get("note", "separate rocprofv3 --pmc passes"))
+    except Exception:
+        return None, "no committed PMC pass for this path"
+
+
+def path_roofline(algo_bytes, gpu_ms, what, traffic):
+    """A path's launches against the HBM roofline: algorithmic bytes of one call / GPU time of one call (HIP events on
+    the stream the launches run on, calls back to back)."""
+    ach = algo_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+    return {"bound": "hbm", "kernels": what, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0], "traffic_source": traffic[1],
+            "gpu_ms_per_call": gpu_ms, "algorithmic_bytes_per_call": algo_bytes}
+
+
 def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
     """The same batches in the reference CLI's own framing (OptimizerPlan::get_chunks_sizes, optimizer/mod.rs:78-98:
     80 frames of 131072 samples), device resident: plain calls, and batch after batch through the pipelined entry
@@ -239,11 +260,15 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
         plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
     torch.cuda.synchronize()
     reps = 40  # (the one synchronisation at the end is ~20 us: spread over enough calls not to show)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(reps):
         plan.compress(d_xs[i % R], outs[0], atsc_amd.AUTO, True, me, 0, stream)
+    ev1.record()
     torch.cuda.synchronize()
     dt_plain = (time.perf_counter() - t0) / reps
+    gpu_ms_plain = ev0.elapsed_time(ev1) / reps  # plain calls enqueue everything on the caller's stream
     total = int(outs[0]["rec_off"][-1].item())
     body = outs[0]["body"][:total].cpu().numpy().tobytes()
     for i in range(8):
@@ -264,16 +289,25 @@ def chunker_framing(ctx, atsc_amd, torch, dev, d_xs, me, stream):
         dp.decompress(d_body, d_out, stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(20):
         dp.decompress(d_body, d_out, stream)
+    ev1.record()
     torch.cuda.synchronize()
     dt_dec = (time.perf_counter() - t0) / 20
+    gpu_ms_dec = ev0.elapsed_time(ev1) / 20
     dp.close()
     plan.close()
+    algo = 8.0 * n + total  # samples read + record bytes written (compress); the reverse (decompress)
     return {"frames": len(sizes), "frame_len": int(sizes[0]), "ratio": 8.0 * n / (total + 12),
-            "compress": {"value": n / dt_plain / 1e6, "unit": "Msamples/s", "ms": dt_plain * 1e3},
+            "compress": {"value": n / dt_plain / 1e6, "unit": "Msamples/s", "ms": dt_plain * 1e3,
+                         "roofline": path_roofline(algo, gpu_ms_plain, "the large tier's launches of one call (k_large_cols243, "
+                                                   "k_large_rows9p, k_large_decide1, k_large_trip243, k_large_decide2, packing), "
+                                                   "first launch to last", pmc_traffic("chunker_compress"))},
             "compress_pipelined": {"value": n / dt_pipe / 1e6, "unit": "Msamples/s", "ms": dt_pipe * 1e3},
-            "decompress": {"value": n / dt_dec / 1e6, "unit": "Msamples/s", "ms": dt_dec * 1e3},
+            "decompress": {"value": n / dt_dec / 1e6, "unit": "Msamples/s", "ms": dt_dec * 1e3,
+                           "roofline": path_roofline(algo, gpu_ms_dec, "k_large_dparse + k_large_trip243<true> (+ k_decompress_large "
+                                                     "for what they leave)", pmc_traffic("chunker_decompress"))},
             "note": "device resident; the reference chunker's framing of the same batches (the atsc CLI's framing)"}
 
 
@@ -282,6 +316,7 @@ C3_SERIES = 4096    # configs[3]: 4096 series x 262144 samples = 2^30
 C3_PER = 262144
 C3_ERROR_PCT = 1
 C3_ROTATE = 3       # resident batches per rank for configs[3] (different series values, same classes); coprime with the 4 scratch sets
+SPINUP_S = 0.25     # untimed spin-up in front of the timed loop (GPU clocks ramp with load)
 XGMI_LINK_GBS = 70.0  # per-direction rate of one xGMI link assumed by --root-weight auto
 
 
@@ -502,11 +537,25 @@ def main():
         body_bytes_b.append(int(outs2[0]["rec_off"][-1].item()))
     chosen = outs2[0]["chosen"].cpu().numpy()
     # (at least one batch through every set of every chain: the sets are built by the first call)
-    for i in range(max(args.warmup, NOUT if pipelined else 0, 1 if world > 1 else 0)):
+    warm_steps = max(args.warmup, NOUT if pipelined else 0, 1 if world > 1 else 0)
+    for i in range(warm_steps):
         step(i, gather=False)
     if pipelined:
         plan.join(stream)
     torch.cuda.synchronize()
+    # Untimed spin-up.  The inputs were generated on the host for seconds while the GPU idled, and its clocks follow the
+    # load: the same 20-step loop takes 103 us per step right behind another loop and 125 us after half a second of idle
+    # (tools/fixed_cost_probe.py, profiles/r04_fixed_cost.txt).  --warmup W stays the minimum; the loop below keeps
+    # stepping (same calls, results discarded) until SPINUP_S seconds of GPU work have passed, so that a short timed
+    # region measures the steady state a longer one does.  Reported as `warmup_effective`.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < SPINUP_S:
+        for i in range(8):
+            step(warm_steps + i, gather=False)
+        warm_steps += 8
+        if pipelined:
+            plan.join(stream)
+        torch.cuda.synchronize()
     gather_mode = None
     if gather_on:
         gather_mode = "size all-gather + point-to-point sends (gather_records)"
@@ -534,6 +583,15 @@ def main():
             gather_mode = ("one asynchronous fixed-capacity gather per step (PipelinedGather: capacity = the largest "
                            "peer's records, the root's stay in place), overlapped with the next step's codecs")
     dt = timed_loop(args.steps, pipelined)
+    # the same loop over ten times the steps (at least 200): what the fill and drain of the chains cost a short timed
+    # region shows as the difference (`steady_state`); never `value`
+    steady = None
+    if world == 1 and pipelined and args.steps < 200:
+        k2 = max(200, 10 * args.steps)
+        dt2 = timed_loop(k2, pipelined)
+        steady = {"steps": k2, "value": units_total * k2 / dt2 / 1e6, "ms_per_step": dt2 / k2 * 1e3,
+                  "note": "the timed loop again over more steps: the chains' fill and drain (about one step's worth of "
+                          "time per timed region) spread over more of them"}
     gathered_sizes = None
     if pg is not None:
         if pg.overflowed():
@@ -610,10 +668,14 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(args.steps):
             dp.decompress(o["body"], d_out, stream)
+        ev1.record()
         torch.cuda.synchronize()
+        dec_gpu_ms = ev0.elapsed_time(ev1) / args.steps  # the decoder's launches run on this stream, back to back
         if world > 1:
             dist.barrier()
         dt_dec = time.perf_counter() - t0
@@ -624,6 +686,9 @@ def main():
         decomp = {"metric": "Msamples/sec decompressed", "value": units_total * args.steps / dt_dec / 1e6,
                   "unit": "Msamples/s", "ms_per_step": dt_dec * 1e3 / args.steps, "steps": args.steps,
                   "batch_mape": mape,
+                  # decompress = record bytes read + 8 B written per output sample
+                  "roofline": path_roofline(nb0 + 8.0 * n_local, dec_gpu_ms, "k_decompress<1,5> (one launch per call)",
+                                            pmc_traffic("decompress_f256")),
                   "config": "BASELINE.json configs[4]: every rank decodes the records of its own shard (device "
                             "resident, frame table parsed once); no collective"}
         del dp, d_out
@@ -704,9 +769,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "traffic_source": "profiles/r03_pmc.json (FETCH_SIZE / WRITE_SIZE come from separate rocprofv3 --pmc passes, "
-                                  "not from this run)",
+                "traffic": pmc_traffic("k_compress_256")[0],
+                "traffic_source": pmc_traffic("k_compress_256")[1],
                 "kernel_ms_avg": k_avg_ms,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -720,6 +784,9 @@ def main():
             if ordered is not None:
                 out["roofline"]["cost_ordered"] = dict(ordered, achieved=algo_bytes / (ordered["kernel_ms_avg"] * 1e-3) / 1e9,
                                                        frac=algo_bytes / (ordered["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        out["warmup_effective"] = warm_steps
+        if steady is not None:
+            out["steady_state"] = steady
         if decomp is not None:
             out["decompress"] = decomp
         if value_no_hint is not None:
