@@ -1213,6 +1213,7 @@ struct FastState {  // at LargeWs::o_front
     uint32_t best_size;
     int32_t best_owner;
     uint32_t poly_final;  // the polynomial ladder ended with its first trip
+    uint32_t forced;      // 1: forced FFT (no competition: the first trip's payload is emitted when the ladder ends there)
     uint32_t poly_size, poly_K, poly_step, poly2_lb, rle_lb;
     uint32_t nlist;       // points in the bucketed list
     double smin, smax, poly_err;
@@ -2533,7 +2534,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     // The fast path (atsc_large_fast.h): frames of 131072 samples under the auto selector, any number of them.
     const bool no_fast = getenv("ATSC_LARGE_NO_FAST") != nullptr;  // (read per launch: the tests switch it)
     const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p != 0 && pre->chunks_n && kp.sparse_inv &&
-                      kp.bounded && kp.mode == ATSC_AUTO && !kp.trial && kp.trial_res == nullptr && diag == nullptr &&
+                      kp.bounded && (kp.mode == ATSC_AUTO || kp.mode == ATSC_FFT || kp.mode == ATSC_POLYNOMIAL) && !kp.trial &&
+                      kp.trial_res == nullptr && diag == nullptr &&
                       (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
     if (fast) {
         e = ensure_dyn_lds(pre->m2_max >= FAST_MD ? (const void *)k_large_decide1_big : (const void *)k_large_decide1,

@@ -356,6 +356,10 @@ __device__ __forceinline__ void large_decide1(
         split_n(smin, mini, fz);
         bitdepth = st.frac ? 0u : bitdepth_of(maxi, mini);
     }
+    // forced `--compressor fft` / `--compressor polynomial` (main.rs:150-162) on this path: the same first trips, no
+    // competition -- the codec is accepted with whatever error its bounded ladder ends on (compressor/mod.rs:86-98)
+    const bool forced_fft = prm.mode == ATSC_FFT, forced_poly = prm.mode == ATSC_POLYNOMIAL;
+    if (smin == smax && (forced_fft || forced_poly)) { FAST_WHY(5); return; }  // (flat frames: the general kernel's shortcuts)
     if (smin == smax) {  // frame/mod.rs:82-88
         if (tid == 0) {
             out[0] = 30;
@@ -397,7 +401,14 @@ __device__ __forceinline__ void large_decide1(
     const bool poly_final = !(round(pcur * 10000.0) > prm.poly_q_hi);  // polynomial.rs:231
     const uint32_t poly_size = 2 + vlen(pK) + vb + 17;
     const uint32_t poly2_lb = 2 + vlen(P.pK[1]) + P.pK[1] * (bitdepth == 0 ? 8u : 1u) + 17;
-    if (poly_final && pcur <= me) offer(poly_size, 1);
+    if (forced_poly) {
+        // polynomial.rs:209-277: the ladder ends with its first trip, or it goes on in the general kernel
+        if (!poly_final) { FAST_WHY(12); return; }
+        fast_emit_poly(out, res[fid], xs, n, bitdepth, pK, pstep, smin, smax, pcur, h2, wsum);
+        if (tid == 0) fs->status = 2;
+        return;
+    }
+    if (!forced_fft && poly_final && pcur <= me) offer(poly_size, 1);
 
     // ---- FFT (fft.rs:288-362) ----
     const float mxf = (float)smax, mnf = (float)smin;
@@ -416,7 +427,7 @@ __device__ __forceinline__ void large_decide1(
     {
         const uint32_t lds64 = cv.own_n + 2 * cv.k_max + cv.cand_max;       // u64 entries from own[] on
         const uint32_t rcap = min(FAST_RLE_ENC_MAX, (8u * lds64) / 28u);     // 28 bytes of LDS per run
-        if (prm.tile_stats && rle_R >= 1 && rle_R <= rcap && can_win(rle_lb, 2) && rle_lb < fft1_size &&
+        if (!forced_fft && prm.tile_stats && rle_R >= 1 && rle_R <= rcap && can_win(rle_lb, 2) && rle_lb < fft1_size &&
             (poly_final || rle_lb < poly2_lb)) {
             const uint32_t R = rle_R;
             unsigned long long *kk = own;                 // value bits of run i
@@ -766,6 +777,7 @@ __device__ __forceinline__ void large_decide1(
         f.bitdepth = bitdepth; f.K1 = K1; f.big = big; f.Z = Z;
         f.best_size = best_size; f.best_owner = best_owner;
         f.poly_final = poly_final ? 1u : 0u;
+        f.forced = forced_fft ? 1u : 0u;
         f.poly_size = poly_size; f.poly_K = pK; f.poly_step = pstep; f.poly2_lb = poly2_lb; f.rle_lb = rle_lb;
         f.nlist = nlist;
         f.smin = smin; f.smax = smax; f.poly_err = pcur;
@@ -1173,15 +1185,20 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     const uint32_t K1 = f.K1;
     const uint32_t fft_size = 1 + vlen(K1) + 9 * K1 + 2 * f.big + 8;
     const bool fft_ends = !(prm.max_err_m < sat_i32(cur * 1000.0));  // fft.rs:334
-    if (fft_ends) {
+    if (f.forced) {
+        // forced FFT: the first trip ends the ladder (the payload is emitted below, whatever the error) or the general
+        // kernel goes on with it
+        if (!fft_ends) { if (tid == 0) fs->status = 0; FAST_WHY(11); return; }
+        best_size = fft_size; best_owner = 0;
+    } else if (fft_ends) {
         if (cur <= me && can_win(fft_size, 0)) { best_size = fft_size; best_owner = 0; }
     } else {
         // the ladder goes on with K2 bins: pruned only if that payload cannot beat a candidate that passes
         const uint32_t K2 = min(P.mf + P.dk1, f.Z);
         if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) fs->status = 0; FAST_WHY(11); return; }
     }
-    if (!f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; FAST_WHY(12); return; }
-    if (can_win(f.rle_lb, 2) || best_owner == 3) { if (tid == 0) fs->status = 0; FAST_WHY(best_owner == 3 ? 14 : 13); return; }
+    if (!f.forced && !f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; FAST_WHY(12); return; }
+    if (!f.forced && (can_win(f.rle_lb, 2) || best_owner == 3)) { if (tid == 0) fs->status = 0; FAST_WHY(best_owner == 3 ? 14 : 13); return; }
     if (best_owner == 1) {
         fast_emit_poly(out, res[fid], xs, n, f.bitdepth, f.poly_K, f.poly_step, f.smin, f.smax, f.poly_err, aux, wsum);
     } else {

@@ -583,6 +583,34 @@ def test_rle_frames_on_the_large_grid_path(ctx, A, oracle, me):
     assert rec == bro[body_off:]
 
 
+@pytest.mark.parametrize("comp,me", [("FFT", ME5), ("FFT", ME1), ("POLYNOMIAL", ME5), ("POLYNOMIAL", ME1)],
+                         ids=["fft-e5", "fft-e1", "poly-e5", "poly-e1"])
+def test_forced_fft_and_polynomial_on_the_large_grid_path(ctx, A, oracle, comp, me):
+    """`--compressor fft` / `--compressor polynomial` (main.rs:150-162) on the chunker's power-of-two chunks: the grid
+    path takes the ladders' first trips (k_large_decide1 / k_large_trip243 / k_large_decide2 with FastState::forced),
+    a ladder that goes on is the general kernel's -- either way the oracle's trips, K, bin order and bytes."""
+    sizes = [8192, 16384, 32768, 65536, 131072]
+    xs, offs = [], [0]
+    for k, n in enumerate(sizes):
+        for c in (0, 1, 2, 3):
+            xs.append(H.synth_series(1900 + k, n, klass=c))
+            offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    off = np.array(offs, dtype=np.uint64)
+    s = P.compare_batch(oracle, ctx, x, off, getattr(A, comp), True, me)
+    _log(P.assert_summary(s, len(offs) - 1, "forced %s on power-of-two large frames, me %.3f" % (comp, me)))
+    out = ctx.decompress_host(s["records"])
+    ref = oracle.decompress_data(A.bro_prefix(len(offs) - 1) + s["records"])
+    for i in range(len(offs) - 1):
+        seg = slice(int(off[i]), int(off[i + 1]))
+        if comp == "POLYNOMIAL":
+            assert np.array_equal(out[seg], ref[seg]), i
+        else:
+            n = int(off[i + 1] - off[i])
+            scale = max(np.max(np.abs(ref[seg])), 1e-30)
+            assert np.max(np.abs(out[seg] - ref[seg])) <= (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5, i
+
+
 def _config3_device_series(torch, dev, n_series, per):
     """configs[3] on the device: series s has class s % 5; classes 0-2 are generated by torch on the
     GPU, the gauge and constant classes on the host."""
