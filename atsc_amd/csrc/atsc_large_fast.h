@@ -424,6 +424,7 @@ __device__ __forceinline__ void large_decide1(
     // (the fast path's condition).  When its payload beats the least either ladder can still store the frame is decided
     // here: no norm is selected, no transform evaluated -- a gauge's 131072-sample frame used to wait for the general
     // kernel (156 us for six of them).  Otherwise nothing changes: the exact size is not offered.
+    uint32_t rle_lb_eff = rle_lb;  // the exact size once it is known: the tightest bound the later verdicts can use
     {
         const uint32_t lds64 = cv.own_n + 2 * cv.k_max + cv.cand_max;       // u64 entries from own[] on
         const uint32_t rcap = min(FAST_RLE_ENC_MAX, (8u * lds64) / 28u);     // 28 bytes of LDS per run
@@ -486,6 +487,7 @@ __device__ __forceinline__ void large_decide1(
                     hb = block_sum_u32<LW>(hb, (double *)(smem + 256), parity);
                 }
                 const uint32_t rle_size = 2 + vlen(D) + hb + rle_ib;
+                rle_lb_eff = rle_size;
                 // frame/mod.rs:113-147: the smallest passing payload, the first of [FFT, Polynomial, RLE] on ties
                 const bool beats_poly = can_win(rle_size, 2) && (poly_final || rle_size < poly2_lb);
                 if (beats_poly && rle_size < fft1_size) {
@@ -529,7 +531,7 @@ __device__ __forceinline__ void large_decide1(
     }
     if (!can_win(fft1_size, 0)) {
         // even the first trip's payload loses to the polynomial, which passes: no transform is evaluated at all
-        if (!(poly_final && pcur <= me) || can_win(rle_lb, 2)) { FAST_WHY(7); return; }
+        if (!(poly_final && pcur <= me) || can_win(rle_lb_eff, 2)) { FAST_WHY(7); return; }
         fast_emit_poly(out, res[fid], xs, n, bitdepth, pK, pstep, smin, smax, pcur, h2, wsum);
         if (tid == 0) fs->status = 2;
         return;
@@ -778,7 +780,7 @@ __device__ __forceinline__ void large_decide1(
         f.best_size = best_size; f.best_owner = best_owner;
         f.poly_final = poly_final ? 1u : 0u;
         f.forced = forced_fft ? 1u : 0u;
-        f.poly_size = poly_size; f.poly_K = pK; f.poly_step = pstep; f.poly2_lb = poly2_lb; f.rle_lb = rle_lb;
+        f.poly_size = poly_size; f.poly_K = pK; f.poly_step = pstep; f.poly2_lb = poly2_lb; f.rle_lb = rle_lb_eff;
         f.nlist = nlist;
         f.smin = smin; f.smax = smax; f.poly_err = pcur;
         f.mxf = mxf; f.mnf = mnf;

@@ -172,7 +172,7 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
             # bin pair's contribution, not by more.  When both ladders stopped at the same K the reported errors are
             # still held together, with the tolerance widened by the decode bar's full noise term (TIE_ERR_FACTOR x).
             if tag == oracle.FFT and chosen_same_k(payload, po):
-                tol = TIE_ERR_FACTOR * (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo) + fft_err_noise(fx))
+                tol = TIE_ERR_FACTOR * (FFT_ERR_ATOL + FFT_ERR_RTOL * abs(eo) + fft_err_noise(fx)) + tie_swap_bound(payload, po, fx)
                 if not (abs(err[i] - eo) <= tol or (np.isnan(err[i]) and np.isnan(eo))):
                     summary["fail"].append((i, "FAIL:err of a tie frame gpu=%r oracle=%r tol=%r" % (err[i], eo, tol)))
         else:
@@ -189,6 +189,28 @@ def compare_batch(oracle, ctx, x, off, compressor, bounded, max_error, level=0, 
 
 
 TIE_ERR_FACTOR = 8.0
+
+
+def tie_swap_bound(payload, payload_o, fx):
+    """Two ladders that stopped at the same K but admitted different bins of (near-)equal norm reconstruct signals
+    that differ, per sample, by at most the swapped bins' amplitudes (2 |c| / L each, L >= n), i.e. their errors by at
+    most that times mean(1 / |g|) -- which is large for a frame with samples next to zero (fuzz seed 517: a 64-sample
+    frame with MAPE 3.0 against 3.7).  Zero when the two admitted the same set."""
+    try:
+        fg, fo = H.parse_fft_payload(payload)[0], H.parse_fft_payload(payload_o)[0]
+    except Exception:
+        return 0.0
+    ng = {p: float(np.hypot(r, i)) for p, r, i in fg}
+    no = {p: float(np.hypot(r, i)) for p, r, i in fo}
+    diff = set(ng) ^ set(no)
+    if not diff:
+        return 0.0
+    amp = sum(ng.get(p, no.get(p)) for p in diff) * 2.0 / max(len(fx), 1)
+    g = np.abs(np.asarray(fx, dtype=np.float64))
+    g = g[np.isfinite(g) & (g > 0)]
+    if not g.size:
+        return 0.0
+    return amp * float(np.mean(np.minimum(1.0 / g, INV_G_CLAMP)))
 
 
 def chosen_same_k(payload, payload_o):

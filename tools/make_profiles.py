@@ -17,7 +17,7 @@ def first(pattern):  # the newest match: gpurun merges every call's files into t
 f = first(os.path.join(G, tag + "_stats", "*", "*kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
-for name in ("bench", "bench_chains", "bench_chains1", "bench_chains4", "stats_bench", "bench_share2"):
+for name in ("bench", "bench_driver", "bench_chains", "bench_chains1", "bench_chains4", "stats_bench", "bench_share2"):
     src = os.path.join(G, "%s_%s.json" % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
@@ -25,11 +25,28 @@ for name in ("bench", "bench_chains", "bench_chains1", "bench_chains4", "stats_b
             open(os.path.join(P, "%s_%s.json" % (tag, name)), "w").write(lines[-1] + "\n")
 for name in ("other_configs", "config3_full_1gpu", "length_probe", "stamps_256", "stamps_2048", "stamps_4096", "queue_probe",
              "chain_stamps_1", "chain_stamps_2", "resident_ab", "dispatch_probe", "gap_probe", "host_path", "large_decode_probe",
-             "large80_decode_kernels", "large_ties"):
+             "large80_decode_kernels", "large_ties", "other_configs_256", "fixed_cost", "fast_left", "c3_kstats16", "c3_kstats256",
+             "fuzz_soak"):
     src = os.path.join(G, "%s_%s.txt" % (tag, name))
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().splitlines() if "amdgpu.ids" not in l)
         open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(txt + "\n")
+
+# 1b. per-launch durations of the headline kernel in that run (plain single-stream calls: no two launches overlap)
+f = first(os.path.join(G, tag + "_stats", "*", "*kernel_trace.csv"))
+if f:
+    rows = [r for r in csv.DictReader(open(f)) if "k_compress<1, 5, false, 256" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(rows, rows[1:])]
+    with open(os.path.join(P, tag + "_kernel_launches.txt"), "w") as o:
+        o.write("k_compress<1,5,false,256>: %d launches of `%s` in start order, duration in us (rocprofv3 --kernel-trace); "
+                "launches that overlap their predecessor: %d\n" % (len(d), "bench.py --chains 1 --no-pipeline --steps 20 --warmup 5",
+                                                                    sum(1 for g in gaps if g < 0)))
+        o.write("mean %.2f  min %.2f  max %.2f  last 20 (the plain-call timed loop the bench line's roofline reads): mean %.2f\n"
+                % (sum(d) / len(d), min(d), max(d), sum(d[-20:]) / len(d[-20:])))
+        for i in range(0, len(d), 20):
+            o.write(" ".join("%.1f" % v for v in d[i:i + 20]) + "\n")
 
 # 2. PMC summary + VALU issue model
 agg = collections.defaultdict(list)
@@ -92,3 +109,43 @@ for nf in (80, 256):
             "(--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE)\n" % (nf, nf * 131072 * 8 / 1e6))
     open(os.path.join(P, "%s_large%d_traffic.txt" % (tag, nf)), "w").write(head + r.stdout)
     print(r.stdout)
+
+
+# 4. decoder traffic + the file bench.py reads for roofline.traffic
+def path_bytes(stats_dir, kernels):
+    """HBM bytes per call of a path = sum over its kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), stats_dir, stats_dir + "_fetch", stats_dir + "_write"],
+                       capture_output=True, text=True)
+    tot = 0.0
+    for l in r.stdout.splitlines()[1:]:
+        w = l.split()
+        if len(w) >= 6 and any(k in l for k in kernels):
+            tot += (float(w[-3]) + float(w[-2])) * 1e6
+    return tot, r.stdout
+
+
+traffic = {"note": "HBM bytes from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE, "
+                   "--kernel-trace only), per launch of the named kernel or per call of the named path; written by tools/make_profiles.py"}
+pj = os.path.join(P, tag + "_pmc.json")
+if os.path.exists(pj):
+    traffic["k_compress_256"] = {"bytes": json.load(open(pj))["hbm_bytes_per_launch"]["total"], "file": tag + "_pmc.json"}
+st = os.path.join(G, tag + "_large80")
+if first(os.path.join(st, "*", "*kernel_stats.csv")):
+    b, _ = path_bytes(st, ("k_large_", "k_pack_", "k_compress_large"))
+    traffic["chunker_compress"] = {"bytes": b, "file": tag + "_large80_traffic.txt"}
+st = os.path.join(G, tag + "_ldec80")
+if first(os.path.join(st, "*", "*kernel_stats.csv")):
+    b, txt = path_bytes(st, ("k_large_dparse", "k_large_trip243<true", "k_decompress_large"))
+    traffic["chunker_decompress"] = {"bytes": b, "file": tag + "_large80_decode_traffic.txt"}
+    open(os.path.join(P, tag + "_large80_decode_traffic.txt"), "w").write(
+        "80 frames x 131072 samples decoded (tools/large_decode_trace.py, NF=80 KLASS=mix; the trace also holds the compress call that "
+        "made the records): per kernel, average duration, HBM bytes read / written per launch\n" + txt)
+st = os.path.join(G, tag + "_dec256")
+if first(os.path.join(st, "*", "*kernel_stats.csv")):
+    b, txt = path_bytes(st, ("k_decompress<",))
+    traffic["decompress_f256"] = {"bytes": b, "file": tag + "_decode256_traffic.txt"}
+    open(os.path.join(P, tag + "_decode256_traffic.txt"), "w").write(
+        "configs[2] in 256-sample frames decoded (tools/decode_trace.py): per kernel, average duration, HBM bytes read / written per launch\n" + txt)
+if len(traffic) > 1:
+    json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
