@@ -118,3 +118,24 @@ dt, tot, body, cod = run_compress(xs, off, atsc_amd.AUTO, True, me1, reps=2)
 report("configs[3] shape: %d series x 262144 auto e=1%% chunker framing" % S, n, dt, tot, cod)
 dtd = run_decompress(body, n, reps=2)
 report("configs[4] decompress of the above (chunker framing)", n, dtd, tot, cod)
+
+# The paper's production shape (VLDB'24 industrial track p.8, section 7: 13 950 signals x 5 432 samples): the reference chunker
+# cuts every series into 4096 + 1024 + 312 samples (optimizer/mod.rs:78-98: power-of-two chunks, a tail of up to 512 samples
+# as it is), so one batch holds three frame lengths -- three k_compress classes.  auto, e = 3 % (the paper's setting);
+# class = series % 5.
+if not quick or os.environ.get("PAPER"):
+    NSER, PER = 13950, 5432
+    me3 = float(np.float32(3) / np.float32(100))
+    xs = np.concatenate([H.synth_series(s, PER, klass=s % 5) for s in range(NSER)])
+    sizes = atsc_amd.chunk_sizes(PER)
+    assert sum(sizes) == PER, sizes
+    off = np.concatenate([[0], np.cumsum(np.tile(sizes, NSER))]).astype(np.uint64)
+    n = len(xs)
+    dt, tot, body, cod = run_compress(xs, off, atsc_amd.AUTO, True, me3, reps=5)
+    report("paper shape: %d series x %d (%s), auto e=3%%" % (NSER, PER, " + ".join(str(v) for v in sizes)), n, dt, tot, cod)
+    dtd = run_decompress(body, n, reps=5)
+    report("decompress of the above", n, dtd, tot, cod)
+    d_list = [xs, np.roll(xs, PER * 7), np.roll(xs, PER * 13)]
+    dtp, totp, same = run_compress_pipelined(d_list, off, atsc_amd.AUTO, True, me3)
+    print(json.dumps({"config": "paper shape, pipelined entry point, 3 batches rotating", "samples": n, "ms": round(dtp * 1e3, 3),
+                      "Msamples_s": round(n / dtp / 1e6, 1), "bytes_equal_plain_call": same}), flush=True)
