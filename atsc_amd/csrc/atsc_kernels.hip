@@ -116,6 +116,12 @@ DEVI void fft_untangle(const DevPlan &P, const float2 *Z, float2 *out, const flo
 // The same transform with the length and the radix sequence known at compile time (frame lengths
 // that get their own instantiation of k_compress): identical arithmetic, operation for operation, but
 // strides, trip counts and the t / stride split are constants.
+// pairs of radix-3 stages fused (fft_stage33_fixed): multi-wavefront frames, whose stages end in a real barrier
+#ifndef ATSC_FUSE33_MIN_W
+#define ATSC_FUSE33_MIN_W 2
+#endif
+template <int W>
+constexpr bool FUSE33 = W >= ATSC_FUSE33_MIN_W;
 template <int W, int M, int SC, int R, int ST>
 DEVI void fft_stage_fixed(const float2 *X, float2 *Y, const float2 *tw)
 {
@@ -153,13 +159,59 @@ DEVI void fft_stage_fixed(const float2 *X, float2 *Y, const float2 *tw)
     }
     __syncthreads();
 }
+// Two radix-3 stages in one pass: the three butterflies p = p' + m' j' (j' = 0 .. 2) of the stage with stride ST write
+// exactly the nine points that the three butterflies (p', q + ST k) of the next stage (stride 3 ST) read, so a thread
+// that runs the former can run the latter on their results in registers -- the same operations in the same order, the
+// results bit for bit those of the two passes -- and the nine points make one trip through LDS and one barrier instead
+// of two.  A 4096-sample frame's transform (M = 3^7) is seven radix-3 stages otherwise: seven barriers of the one
+// workgroup its CU holds.
+template <int W, int M, int SC, int ST>
+DEVI void fft_stage33_fixed(const float2 *X, float2 *Y, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    constexpr uint32_t nb = M / 9, m1 = (M / ST) / 3, m2 = m1 / 3, sm = ST * m1, ST2 = 3 * ST;
+    const float h = 0.8660254037844386f;
+    auto bfly = [&](const float2 a0, const float2 a1, const float2 a2, const uint32_t tb, float2 &y0, float2 &y1, float2 &y2) {
+        const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+        const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+        const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+        const float2 t3 = make_float2(h * d.y, -h * d.x);
+        y0 = make_float2(a0.x + t1.x, a0.y + t1.y);
+        y1 = cmul_conj_tw(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
+        y2 = cmul_conj_tw(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
+    };
+    for (uint32_t t = tid_now<W>(); t < nb; t += T) {
+        const uint32_t p2 = t / ST, q = t - p2 * ST;  // p' < m2
+        float2 y[3][3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const uint32_t p = p2 + m2 * jj;
+            const uint32_t ib = q + ST * p;
+            bfly(X[ib], X[ib + sm], X[ib + 2 * sm], p * ST * SC, y[jj][0], y[jj][1], y[jj][2]);
+        }
+        const uint32_t tb2 = p2 * ST2 * SC;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t ob = (q + ST * k) + ST2 * (3 * p2);
+            float2 z0, z1, z2;
+            bfly(y[0][k], y[1][k], y[2][k], tb2, z0, z1, z2);
+            Y[ob] = z0;
+            Y[ob + ST2] = z1;
+            Y[ob + 2 * ST2] = z2;
+        }
+    }
+    __syncthreads();
+}
 // the stage list of the host (build_plan_entry: 4s, then 2s, then 3s) unrolled at compile time,
-// e.g. n = 256: L = 288, M = 144 = 4 * 4 * 3 * 3
+// e.g. n = 256: L = 288, M = 144 = 4 * 4 * 3 * 3; pairs of radix-3 stages run fused (fft_stage33_fixed)
 template <int W, int M, int SC, int REM = M, int ST = 1>
 DEVI float2 *fft_forward_fixed(float2 *X, float2 *Y, const float2 *tw)
 {
     if constexpr (REM == 1) {
         return X;
+    } else if constexpr (FUSE33<W> && REM % 2 != 0 && REM % 9 == 0) {
+        fft_stage33_fixed<W, M, SC, ST>(X, Y, tw);
+        return fft_forward_fixed<W, M, SC, REM / 9, ST * 9>(Y, X, tw);
     } else {
         constexpr int R = (REM % 4 == 0) ? 4 : (REM % 2 == 0) ? 2 : 3;
         fft_stage_fixed<W, M, SC, R, ST>(X, Y, tw);
@@ -249,6 +301,66 @@ DEVI void block_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint3
             __syncthreads();
         }
     }
+}
+
+// Sorting a few hundred DISTINCT keys by counting: a key's place is the number of smaller keys.  The bitonic
+// networks above are log2(P2) (log2(P2) + 1) / 2 rounds, each ending in the whole workgroup's barrier -- 36 rounds for
+// the 176 keys of a 4096-sample frame's first admission order, with 88 of 1024 threads at work -- where this is four
+// barriers and count^2 / T compares per thread.  p threads share a key (a power of two, at most 16): each counts over
+// its stride of the keys and adds its share to the key's rank in LDS.  tmp: count u64 + count u32 of scratch.
+template <int W>
+DEVI void block_rank_sort(uint64_t *keys, uint64_t *tmp, uint32_t count)
+{
+    constexpr uint32_t T = 64 * W;
+    const uint32_t tid = tid_now<W>();
+    uint32_t *rank = (uint32_t *)(tmp + count);
+    uint32_t p = 1;
+    while (p < 16 && 2 * p * count <= T) p <<= 1;
+    for (uint32_t i = tid; i < count; i += T) rank[i] = 0;
+    __syncthreads();
+    for (uint32_t w = tid; w < p * count; w += T) {
+        const uint32_t i = w / p, q = w - i * p;
+        const uint64_t mine = keys[i];
+        uint32_t r = 0;
+        for (uint32_t j = q; j < count; j += p) r += keys[j] < mine ? 1u : 0u;
+        if (p == 1) rank[i] = r;
+        else if (r) atomicAdd(&rank[i], r);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < count; i += T) tmp[rank[i]] = keys[i];
+    __syncthreads();
+    for (uint32_t i = tid; i < count; i += T) keys[i] = tmp[i];
+    __syncthreads();
+}
+// The same for RLE run records (block_sort_runs' order: value bits, then the record, i.e. the start).  tmp: 2 count u32.
+template <int W>
+DEVI void block_rank_sort_runs(uint32_t *rec, const double *xs, uint32_t count, uint32_t *tmp)
+{
+    constexpr uint32_t T = 64 * W;
+    const uint32_t tid = tid_now<W>();
+    uint32_t *rank = tmp + count;
+    uint32_t p = 1;
+    while (p < 16 && 2 * p * count <= T) p <<= 1;
+    for (uint32_t i = tid; i < count; i += T) rank[i] = 0;
+    __syncthreads();
+    for (uint32_t w = tid; w < p * count; w += T) {
+        const uint32_t i = w / p, q = w - i * p;
+        const uint32_t ra = rec[i];
+        const uint64_t ka = (uint64_t)__double_as_longlong(xs[ra & 0xffffu]);
+        uint32_t r = 0;
+        for (uint32_t j = q; j < count; j += p) {
+            const uint32_t rb = rec[j];
+            const uint64_t kb = (uint64_t)__double_as_longlong(xs[rb & 0xffffu]);
+            r += (kb < ka || (kb == ka && rb < ra)) ? 1u : 0u;
+        }
+        if (p == 1) rank[i] = r;
+        else if (r) atomicAdd(&rank[i], r);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < count; i += T) tmp[rank[i]] = rec[i];
+    __syncthreads();
+    for (uint32_t i = tid; i < count; i += T) rec[i] = tmp[i];
+    __syncthreads();
 }
 
 // --------------------------------------------------------------------------------------------
@@ -607,9 +719,13 @@ __device__ __forceinline__ void compress_frame(
             rrec[r] = (st << 16) | ends[r];
         }
         __syncthreads();
-        uint32_t p2 = 1;
-        while (p2 < R) p2 <<= 1;
-        block_sort_runs<W>(rrec, xs, R, p2);
+        if (R <= 512 && 2 * R <= n + 2) {
+            block_rank_sort_runs<W>(rrec, xs, R, aux);  // (aux is free between the scan above and the flags below)
+        } else {
+            uint32_t p2 = 1;
+            while (p2 < R) p2 <<= 1;
+            block_sort_runs<W>(rrec, xs, R, p2);
+        }
         for (uint32_t i = tid; i < R; i += T)
             aux[i] = (i == 0 || run_key(rrec[i]) != run_key(rrec[i - 1])) ? 1u : 0u;
         __syncthreads();
@@ -1140,9 +1256,13 @@ __device__ __forceinline__ void compress_frame(
                         if ((mine[c] & resolved) <= prefix) keys[atomicAdd(&hist[258], 1u)] = mine[c];
                     __syncthreads();
                 }
-                uint32_t p2 = 1;
-                while (p2 < nk) p2 <<= 1;
-                block_sort<W, true>(keys, nullptr, nk, p2);
+                if (nk <= 1024 && 5 * nk / 2 + 2 <= bins) {
+                    block_rank_sort<W>(keys, keys + nk, nk);  // (behind the nk keys the buffer is free: keys_fresh is off)
+                } else {
+                    uint32_t p2 = 1;
+                    while (p2 < nk) p2 <<= 1;
+                    block_sort<W, true>(keys, nullptr, nk, p2);
+                }
                 sorted_n = nk;
             };
 
