@@ -335,6 +335,55 @@ DEVI double wave_minmax_f64(double v)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+// The statistics of a multi-wavefront frame in ONE exchange: minimum, maximum, "any fractional sample" and the packed
+// run count / index bytes of the RLE bound (rle.rs:142-189).  Four block reductions one after the other are four
+// barriers of the whole workgroup, each followed by every thread reading all W partials; here every wavefront leaves
+// its four partials, one barrier, lane l combines the partials of wavefront l & 15 inside its row of 16 lanes (four DPP
+// steps per value), and a second barrier frees the scratch.  Min / max / or / integer sum: nothing depends on the order.
+// red: 32 doubles, wsum: 32 words behind them (the layout of the block_* helpers).  W <= 16.
+struct BlockStats {
+    double mn, mx;
+    uint32_t frac, pk;
+};
+template <int W>
+DEVI BlockStats block_stats4(double mn, double mx, uint32_t frac, uint32_t pk, double *red, uint32_t *wsum)
+{
+    static_assert(W >= 2 && W <= 16, "block_stats4: 2 .. 16 wavefronts");
+    const uint32_t tid = tid_now<W>(), lane = tid & 63u, wv = tid >> 6;
+    mn = wave_minmax_f64<true>(mn);
+    mx = wave_minmax_f64<false>(mx);
+    const uint32_t wfr = __ballot(frac != 0) ? 1u : 0u;
+    pk = wave_sum_u32(pk);
+    if (lane == 0) { red[wv] = mn; red[16 + wv] = mx; wsum[wv] = wfr; wsum[16 + wv] = pk; }
+    __syncthreads();
+    const uint32_t src = lane & 15u;
+    const bool valid = src < (uint32_t)W;
+    double a = red[valid ? src : 0u], b = red[16 + (valid ? src : 0u)];
+    uint32_t f = valid ? wsum[src] : 0u, k = valid ? wsum[16 + src] : 0u;
+#define ATSC_ROW_STEP(CTRL)                                            \
+    {                                                                  \
+        const double oa = dpp_f64_full<CTRL>(a), ob = dpp_f64_full<CTRL>(b); \
+        a = fmin(oa, a);                                               \
+        b = fmax(ob, b);                                               \
+        f |= dpp_u32<CTRL, 0xf>(f);                                    \
+        k += dpp_u32<CTRL, 0xf>(k);                                    \
+    }
+    ATSC_ROW_STEP(0xb1)
+    ATSC_ROW_STEP(0x4e)
+    ATSC_ROW_STEP(0x124)
+    ATSC_ROW_STEP(0x128)
+#undef ATSC_ROW_STEP
+    __syncthreads();
+    // (every lane holds the same four values; said so -- readfirstlane -- because everything the frame derives from them
+    // (the clamp range, the bit depth, the RLE bound, payload sizes) is scalar work only if the compiler knows: taken
+    // from DPP results it kept all of it in vector registers, 87 -> 117 VGPRs for the 1024-sample instantiation)
+    BlockStats r;
+    r.mn = lane_f64(a, 0);
+    r.mx = lane_f64(b, 0);
+    r.frac = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+    r.pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    return r;
+}
 template <int W, bool IsMin>
 DEVI double block_minmax_f64(double v, double *red, int &parity)
 {

@@ -548,6 +548,8 @@ __device__ __forceinline__ void compress_frame(
     // value (strict compares), so +0.0 / -0.0 resolve as the sequential scan does ---------------
     double smin, smax;
     uint32_t bitdepth;
+    uint32_t stat_pk = 0;       // multi-wavefront frames: (index varint bytes << 13 | run count), summed with the statistics
+    bool stat_pk_done = false;
     {
         double mn, mx;
         uint32_t fr_any = 0;
@@ -561,11 +563,21 @@ __device__ __forceinline__ void compress_frame(
                 fr_any |= frac_nonzero(v) ? 1u : 0u;
                 if (v > mx) mx = v;
                 if (v < mn) mn = v;
+                if constexpr (W > 1) {  // the RLE bound's run starts and index bytes ride on the same walk
+                    const double b = xs[j ? j - 1 : 0];
+                    if (j == 0 || v != b) stat_pk += (vlen(j) << 13) | 1u;
+                }
             });
         }
-        mn = block_minmax_f64<W, true>(mn, red, parity);
-        mx = block_minmax_f64<W, false>(mx, red, parity);
-        fr_any = block_or_u32<W>(fr_any, red, parity);
+        if constexpr (W > 1) {
+            const BlockStats bs = block_stats4<W>(mn, mx, fr_any, stat_pk, red, wsum);
+            mn = bs.mn; mx = bs.mx; fr_any = bs.frac; stat_pk = bs.pk;
+            stat_pk_done = true;
+        } else {
+            mn = block_minmax_f64<W, true>(mn, red, parity);
+            mx = block_minmax_f64<W, false>(mx, red, parity);
+            fr_any = block_or_u32<W>(fr_any, red, parity);
+        }
         // Samples that compare equal to the extreme value have the same bits, except for zeros
         // (+0.0 == -0.0): only then the scan's "first occurrence" has to be looked up.  A NaN in
         // data[0] poisons every compare and the scan keeps data[0] (mn, mx are x0 then).
@@ -812,15 +824,19 @@ __device__ __forceinline__ void compress_frame(
     if (run_rle) {
         // run starts: j == 0 or x[j] != x[j-1]; every start index costs a varint
         uint32_t pk = 0;  // (sum of index varint bytes) << 13 | run count   (n <= 4096)
-        if (reg_stats) {
-            pk = rs_pk;  // counted from the registers the samples arrived in
+        if (stat_pk_done) {
+            pk = stat_pk;  // summed with the statistics (block_stats4)
         } else {
-            for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
-                const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
-                if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
-            });
+            if (reg_stats) {
+                pk = rs_pk;  // counted from the registers the samples arrived in
+            } else {
+                for_strided<FN, T, SPL>(tid, n, [&](uint32_t j) {
+                    const double a = xs[j], b = xs[j ? j - 1 : 0];  // (both loads unconditional: no branch around an LDS round trip)
+                    if (j == 0 || a != b) pk += (vlen(j) << 13) | 1u;
+                });
+            }
+            pk = block_sum_u32<W>(pk, red, parity);
         }
-        pk = block_sum_u32<W>(pk, red, parity);
         rle_R = pk & 0x1fffu;
         rle_ib = pk >> 13;
         const uint32_t minval = (bitdepth == 0) ? 8u : 1u;
