@@ -14,6 +14,11 @@
 
 namespace atsc {
 
+#ifndef ATSC_DEC_FFT_MIN_K
+#define ATSC_DEC_FFT_MIN_K 16
+#endif
+constexpr uint32_t DEC_FFT_MIN_K = ATSC_DEC_FFT_MIN_K;  // stored bins from which a multi-wavefront frame decodes by inverse FFT
+
 template <int W, int SPL>
 __global__ __launch_bounds__(64 * W) void k_decompress(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
@@ -307,6 +312,73 @@ __global__ __launch_bounds__(64 * W) void k_decompress(
         const double mxd = (double)mxf, mnd = (double)mnf;
         const float Lf = (float)L;
         const uint32_t magicL = P.magicL;
+        // Multi-wavefront frames with more than a handful of stored bins: one inverse transform in LDS -- what the
+        // reference runs (fft.rs:446-456: an f32 inverse FFT of the mirrored spectrum) -- instead of the direct sum,
+        // which is K x L multiply-adds in f64 (a 4096-sample frame with 80 bins: 16 us on its CU, which holds one
+        // such workgroup; `tools/decode_length_probe.py`: 59 Gsamples/s where 2048-sample frames decode at 98).
+        // Even L: the Hermitian spectrum X folds into Zf = E + i O of length M = L / 2 (E, O: the transforms of the
+        // even and the odd samples, E[k] = (X[k] + conj X[M-k]) / 2, O[k] = w^-k (X[k] - conj X[M-k]) / 2) and
+        // idft_L = 2 idft_M: even sample -> re, odd -> im (the inverse of the encoder's untangle step, as in
+        // k_large_trip243<true>).  Odd L: the full mirrored spectrum.  The inverse runs as conj(FFT(conj(.))) through
+        // the encoder's forward stages.  sel[] (in A) is consumed before A is reused.
+        if constexpr (W > 1) {
+            const uint32_t M = P.M;
+            if (!P.direct && K >= DEC_FFT_MIN_K && 12u * K <= P.ab_half) {
+                float2 *A = (float2 *)AB, *B = (float2 *)(AB + P.ab_half);
+                const float2 *Y;
+                if (P.half) {
+                    for (uint32_t k = tid; k <= M; k += T) B[k] = make_float2(0.0f, 0.0f);
+                    __syncthreads();
+                    for (uint32_t i = tid; i < K; i += T) {
+                        const Sel e = sel[i];
+                        if (own[e.pos] == i + 1) B[e.pos] = make_float2(e.re, e.im);  // (mirrored positions: <= L / 2 = M)
+                    }
+                    __syncthreads();
+                    for (uint32_t k = tid; k < M; k += T) {
+                        const float2 xk = B[k], xm = B[M - k];
+                        const float2 w = tw[k];
+                        const float2 E = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+                        const float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
+                        const float2 O = make_float2(0.5f * (D.x * w.x - D.y * w.y), 0.5f * (D.x * w.y + D.y * w.x));
+                        A[k] = make_float2(E.x - O.y, -(E.y + O.x));  // conj(E + i O)
+                    }
+                    __syncthreads();
+                    Y = fft_forward<W>(P, A, B, tw);
+                } else {
+                    for (uint32_t k = tid; k < L; k += T) B[k] = make_float2(0.0f, 0.0f);
+                    __syncthreads();
+                    for (uint32_t i = tid; i < K; i += T) {
+                        const Sel e = sel[i];
+                        if (own[e.pos] == i + 1) {
+                            B[e.pos] = make_float2(e.re, -e.im);                    // conj X[pos]
+                            if (e.pos != 0) B[L - e.pos] = make_float2(e.re, e.im);  // conj X[L - pos] = X[pos]
+                        }
+                    }
+                    __syncthreads();
+                    Y = fft_forward<W>(P, B, A, tw);
+                }
+#pragma unroll
+                for (int m = 0; m < SPL; ++m) {
+                    const uint32_t j = tid + m * T;
+                    if (j < n) {
+                        const uint32_t jj = j + pre;
+                        float re;
+                        if (P.half) {
+                            const float2 y = Y[jj >> 1];
+                            re = (jj & 1u) ? -2.0f * y.y : 2.0f * y.x;
+                        } else {
+                            re = Y[jj].x;
+                        }
+                        const float v = re / Lf;  // fft.rs:460  f.re / len (f32)
+                        double o = round((double)v * 100000.0) / 100000.0;
+                        if (o > mxd) o = mxd;
+                        if (o < mnd) o = mnd;
+                        out[j] = o;
+                    }
+                }
+                return;
+            }
+        }
         // A thread owns samples tid, tid + T, ... (at most SPL of them: n <= L <= 64 W SPL); the entries are the
         // outer loop so that an entry's constants and its twiddle index walk (pos * (j + pre) mod L,
         // advanced by pos * T mod L) are set up once.  Per sample the terms still add up in stream order,

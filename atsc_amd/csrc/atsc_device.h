@@ -525,6 +525,69 @@ DEVI void block_sort(uint64_t *keys, uint32_t *pay, uint32_t count, uint32_t P2)
 }
 
 // --------------------------------------------------------------------------------------------
+// forward transform, complex f32, unnormalised, e^{-i...}  (rustfft plan_fft_forward): Stockham autosort of length
+// M = P.M, radices 4/2/3 from the plan; tw[t] = (cos, sin)(2 pi t / L) is the length-L table, so the stage twiddle
+// w_M^e is tw[e * P.sc].  Returns the result buffer.  Shared by the encoder (atsc_kernels.hip) and the decoder's
+// inverse transform (atsc_decode.hip).
+// --------------------------------------------------------------------------------------------
+DEVI float2 cmul_conj_tw(float2 v, float2 w)  // v * (w.x - i w.y)
+{
+    return make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+}
+template <int W>
+DEVI float2 *fft_forward(const DevPlan &P, float2 *X, float2 *Y, const float2 *tw)
+{
+    constexpr int T = 64 * W;
+    const uint32_t M = P.M, sc = P.sc;
+    uint32_t ncur = M, st = 1;
+    for (uint32_t s = 0; s < P.nstages; ++s) {
+        const uint32_t r = P.radix[s];
+        const uint32_t m = ncur / r;
+        const uint32_t nb = M / r;
+        const uint32_t magic = P.stmagic[s];
+        const uint32_t sm = st * m;
+        for (uint32_t t = tid_now<W>(); t < nb; t += T) {
+            const uint32_t p = (st == 1) ? t : __umulhi(t, magic);  // t / st
+            const uint32_t q = t - p * st;
+            const uint32_t ib = q + st * p;        // + st*m*j
+            const uint32_t ob = q + st * (r * p);  // + st*k
+            const uint32_t tb = p * st * sc;       // twiddle index step per k
+            if (r == 4) {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm], a3 = X[ib + 3 * sm];
+                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+                const float2 t3 = make_float2(d.y, -d.x);  // d * (-i)
+                Y[ob] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(t1.x + t3.x, t1.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmul_conj_tw(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * tb]);
+                Y[ob + 3 * st] = cmul_conj_tw(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * tb]);
+            } else if (r == 2) {
+                const float2 a0 = X[ib], a1 = X[ib + sm];
+                Y[ob] = make_float2(a0.x + a1.x, a0.y + a1.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(a0.x - a1.x, a0.y - a1.y), tw[tb]);
+            } else {
+                const float2 a0 = X[ib], a1 = X[ib + sm], a2 = X[ib + 2 * sm];
+                const float2 t1 = make_float2(a1.x + a2.x, a1.y + a2.y);
+                const float2 t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+                const float2 d = make_float2(a1.x - a2.x, a1.y - a2.y);
+                const float h = 0.8660254037844386f;
+                const float2 t3 = make_float2(h * d.y, -h * d.x);  // -i * h * d
+                Y[ob] = make_float2(a0.x + t1.x, a0.y + t1.y);
+                Y[ob + st] = cmul_conj_tw(make_float2(t2.x + t3.x, t2.y + t3.y), tw[tb]);
+                Y[ob + 2 * st] = cmul_conj_tw(make_float2(t2.x - t3.x, t2.y - t3.y), tw[2 * tb]);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = X; X = Y; Y = tmp;
+        ncur = m;
+        st *= r;
+    }
+    return X;
+}
+
+// --------------------------------------------------------------------------------------------
 // Catmull-Rom / linear piecewise evaluation at integer x (splines 4.3.1 semantics, restated in
 // oracle/atsc_oracle.c spline_clamped_sample) with the closed-form segment index.
 // keys: T(k) = k*step for k < K-1, T(K-1) = n-1.   polynomial.rs:329-373
