@@ -171,3 +171,50 @@ def test_compress_frames_sharded_matches_one_context():
             assert np.array_equal(err, want_err, equal_nan=True)
             for c in ctxs:
                 c.close()
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[2]
+import torch, torch.distributed as dist
+from atsc_amd import parallel
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+body = torch.arange(0, 5000, dtype=torch.int64, device=dev).to(torch.uint8)
+nb = torch.tensor([4321], dtype=torch.int64, device=dev)
+out, sizes = parallel.gather_records(dist, torch, body, nb, 0, 1)
+assert sizes == [4321] and torch.equal(out, body[:4321])
+pg = parallel.PipelinedGather(dist, torch, 0, 1, dev, 4321)
+side = torch.cuda.Stream(device=dev)
+for step in range(4):
+    slot = step % 2
+    pg.before_produce(slot)
+    with torch.cuda.stream(side):
+        pg.submit(slot, body, nb)
+pg.drain()
+torch.cuda.synchronize()
+assert not pg.overflowed()
+segs, sizes = pg.result(1)
+assert sizes == [4321] and torch.equal(segs[0], body[:4321])
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+def test_record_gather_runs_on_the_rccl_backend_with_one_rank():
+    """The exchange `bench.py --gpus N` uses -- gather_records and PipelinedGather (an all-reduce, an 8-byte all-gather,
+    one asynchronous fixed-capacity gather per step issued from a side stream) -- on the backend the 8-GPU run uses
+    ("nccl" = RCCL), with the one rank a one-GPU box allows: the calls, dtypes and stream use are RCCL's to accept or
+    refuse even when nothing crosses a link.  (Two ranks on one device are refused by RCCL: the two-process tests
+    above carry their bytes over gloo.)"""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT, str(_free_port())], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
