@@ -36,7 +36,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/${tag}_dec25
 for ns in 16 256; do NS=$ns bash tools/large_c3_kstats.sh $G/${tag}_c3k$ns > $G/${tag}_c3_kstats$ns.txt 2>&1; done
 fi
 if [ $part = all ] || [ $part = probes ]; then
-echo "== other configs"; python3 tools/bench_configs.py quick > $G/${tag}_other_configs.txt 2>&1
+echo "== other configs"; PAPER=1 python3 tools/bench_configs.py quick > $G/${tag}_other_configs.txt 2>&1
 python3 tools/bench_configs.py > $G/${tag}_other_configs_256.txt 2>&1
 echo "== length probe"; python3 tools/length_probe.py > $G/${tag}_length_probe.txt 2>&1
 echo "== fixed cost"; python3 tools/fixed_cost_probe.py > $G/${tag}_fixed_cost.txt 2>&1
