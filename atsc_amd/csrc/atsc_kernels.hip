@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(256) void k_pack_emit_big(const DevFrame *__restric
 // Few frames (a batch of large frames: 80 records of kilobytes): one launch instead of three.  A workgroup per frame
 // adds up the record lengths of the frames in front of its own -- at most PACK_SMALL_MAX of them, 16 bytes each, L2
 // resident -- and copies its payload 16 bytes per lane.  Same bytes as k_pack_scan1 + k_pack_emit (+ _big).
-constexpr uint32_t PACK_SMALL_MAX = 1024;
+constexpr uint32_t PACK_SMALL_MAX = 2048;  // (1280 frames of 8192 samples: one launch of 6 us instead of three, 14 us)
 __global__ __launch_bounds__(256) void k_pack_small(const DevFrame *__restrict__ frames, const DevResult *__restrict__ res,
                                                     uint32_t n_frames, const uint8_t *__restrict__ slots,
                                                     uint8_t *__restrict__ body, uint64_t body_cap,
@@ -2023,7 +2023,7 @@ __global__ __launch_bounds__(256) void k_pack_small(const DevFrame *__restrict__
     before = wave_sum_u32(before);
     if ((tid & 63) == 0) ws[tid >> 6] = before;
     __syncthreads();
-    uint64_t off = (uint64_t)ws[0] + ws[1] + ws[2] + ws[3];  // (n_frames <= 1024 records of < 4 MB: the 32-bit partial sums hold)
+    uint64_t off = (uint64_t)ws[0] + ws[1] + ws[2] + ws[3];  // (a wavefront's share: <= 512 records of < 2.3 MB, the 32-bit partial sums hold)
     if (chain_in) off += *chain_in;
     const DevFrame fr = frames[f];
     const DevResult r = res[f];
