@@ -1515,7 +1515,10 @@ def test_decompress_foreign_fft_streams(ctx, A, oracle):
     entries overwrite), positions above L/2 (mirrored), entries of both widths in one stream."""
     import struct
     rng = np.random.default_rng(77)
-    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500), (256, 40), (1000, 300), (100, 30), (40, 12)):
+    # (513 ... 4096 samples with 16 or more entries: the decoder's inverse transform in LDS, even and odd L; fewer
+    # entries, or more than fit beside the spectrum: the direct sum)
+    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500), (256, 40), (1000, 300), (100, 30), (40, 12),
+                   (2048, 500), (4096, 1200), (4096, 1700), (3000, 90), (600, 17), (1024, 15), (2048, 16)):
         L = int(oracle.next_size(n)) if n >= 128 else n  # fft.rs:432-444: no padding below 128 samples
         pos = rng.integers(0, L, size=cnt)
         pos[: cnt // 3] = rng.integers(0, min(251, L), size=cnt // 3)  # one-byte positions among the wide ones
