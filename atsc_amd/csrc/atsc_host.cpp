@@ -2078,6 +2078,23 @@ static int dplan_create_range(atsc_ctx *ctx, const uint8_t *body, uint64_t body_
         for (uint32_t pi : lp)
             if (p->tabs.plans[pi].sp_mf) p->large_sp_tiles = std::max(p->large_sp_tiles, (p->tabs.plans[pi].sp_md + 7) / 8);
         if (getenv("ATSC_LARGE_DECODE_ONE_KERNEL")) p->large_sp_tiles = 0;
+        // When every large FFT frame is one the decoder's grid path takes (k_large_dparse: a power-of-two chunk whose
+        // payload fits its LDS window and holds at most 1344 entries -- what this library's first ladder trip stores),
+        // the general decoder behind it has no FFT frame to bucket, and the launch of its tile grid (4.7 us of nothing)
+        // is left out; should k_large_dparse leave such a frame alone after all (a malformed or flat payload), the
+        // general kernel then transforms it by itself.
+        if (p->large_sp_tiles && !getenv("ATSC_LARGE_NO_FAST")) {
+            bool all_fast = true;
+            for (size_t f = 0; f < frames.size() && all_fast; ++f) {
+                if (cls[f] != CLASS_LARGE || frames[f].tag != ATSC_FFT) continue;
+                const DevPlan &q = p->tabs.plans[frames[f].plan];
+                const uint32_t p9 = q.f4_m2 / 9u;
+                const bool geo = q.f4_m1 == 243 && q.half && p9 * 9u == q.f4_m2 && p9 >= 2 && p9 <= 32 && (p9 & (p9 - 1)) == 0 &&
+                                 q.mf <= 1344 && !(q.pre & 1u) && !(frames[f].n & 1u);
+                all_fast = geo && frames[f].payload_len + 4u <= 16384u && frames[f].payload_len <= 11u * 1344u + 12u;
+            }
+            if (all_fast) p->large_sp_tiles = 0;
+        }
     }
     lap("class lists");
     int rc = upload_tables(ctx, p->tabs, up);

@@ -834,6 +834,16 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     const FastState *fs = (const FastState *)(ws + lay.o_front);
     if (fast_geo(P).lg != (uint32_t)LG) return;
     if constexpr (DECODE) {
+        if (fs->status == 5) {  // a Constant frame: this workgroup fills piece blockIdx.x
+            const uint32_t n = P.n, pieces = fast_geo(P).tiles;
+            if (blockIdx.x >= pieces) return;
+            const double v = fs->smin;
+            double *out = frame_out(outp, fr);
+            const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / pieces);
+            const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / pieces);
+            for (uint32_t j = i0 + tid; j < i1; j += CT) out[j] = v;
+            return;
+        }
         if (fs->status == 4) {
             // An RLE frame k_large_dparse prepared: this workgroup writes piece blockIdx.x of the frame.  A wavefront takes
             // 64 runs at a time, one per lane (start, next start, value), and writes them one after the other, 64 samples a
@@ -1255,7 +1265,8 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
     const FastGeo geo = fast_geo(P);
-    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL && fr.tag != ATSC_RLE) || !geo.ok || (P.pre & 1u) || (fr.n & 1u)) return;
+    if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL && fr.tag != ATSC_RLE && fr.tag != ATSC_CONSTANT) || !geo.ok || (P.pre & 1u) ||
+        (fr.n & 1u)) return;
     // LDS: [hdr 512][payload window STG_BYTES][tab 1024 u32][pos FAST_K_MAX u32 + dead FAST_K_MAX u32][zl][zs]
     uint32_t *bc = (uint32_t *)smem;
     float *bcf = (float *)(smem + 64);
@@ -1287,6 +1298,21 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     // (next^64), a single thread hops from group to group of 64 entries, and the sixteen wavefronts parse the
     // groups side by side.
     uint8_t *win = smem + 512 + mis;
+    if (fr.tag == ATSC_CONSTANT) {
+        // constant.rs:141-144: one value for the whole frame; the tile grid writes it (status 5), a piece per workgroup,
+        // instead of one workgroup of the general decoder writing a megabyte alone
+        if (tid < 64) {
+            RdS r{pay, fr.payload_len, 0, false, win, 0, fr.payload_len, STG_BYTES};
+            (void)rds_u8(r);
+            const uint32_t bd = (uint32_t)rds_varint(r);
+            double v = 0.0;
+            bool bad = bd > 3;
+            if (!bad) v = rds_value(r, bd);
+            bad = bad || r.bad;
+            if (tid == 0 && !bad) { fs->smin = v; fs->status = 5; }
+        }
+        return;
+    }
     if (fr.tag == ATSC_RLE) {
         // RLE frame (rle.rs:204-236): groups of (value, count, count run starts).  One wavefront walks the group headers
         // (below), every thread decodes starts, and the keys (start << 32 | group) are sorted in LDS (runs that share a
