@@ -876,7 +876,13 @@ __device__ __forceinline__ void compress_frame(
                     if (W == 1) frame_prio(poly_trips);
                     poly_step = step;
                     poly_K = K;
-                    if (IDW && step > 1 && idw) {
+                    // A trip whose (step, K) are the trip's before -- n / points rounds to the same step for two point
+                    // counts in a row: 256 samples, 103 and 128 points, step 2 -- evaluates the same spline on the same
+                    // samples; the reference does it again (polynomial.rs:231-270), here the error (or the lower bound that
+                    // already failed it) is simply kept: the loop only got here because that value failed.
+                    const bool same_trip = ti > 0 && step == P.pstep[ti - 1] && K == P.pK[ti - 1];
+                    if (same_trip) {
+                    } else if (IDW && step > 1 && idw) {
                         // polynomial.rs:375-393 + inverse_distance_weight 0.1.1 (oracle: poly_idw_to_data):
                         // every sample sums over ALL K points in ascending order; an exact hit returns the
                         // point's value.  O(n K) per trip, forced `--compressor idw` only.
