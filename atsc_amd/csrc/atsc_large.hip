@@ -2564,8 +2564,9 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             }
             kp.tile_stats = tst ? 1u : 0u;
             if (tst) {  // the row pass and the first polynomial trip's pieces in one launch
+                // (bit 1: the column tiles' statistics are there -- a Constant frame's workgroups leave at once)
                 launch_rows9p(pre->rows9p, tiles23, pre->chunks_n * (LCH / PCH), nb, s, samples, frames, ids + b0, plans, twpool,
-                              ws, ws_stride, (int)kp.sparse_inv);
+                              ws, ws_stride, (int)(kp.sparse_inv ? 1 : 0) | 2);
             } else {
                 hipLaunchKernelGGL(k_large_poly1, dim3(pre->chunks_n, nb), dim3(LT), 0, s, samples, frames, ids + b0, plans,
                                    ws, ws_stride, 0);

@@ -278,6 +278,23 @@ DEVI void dft_pow2f(float2 (&a)[N])  // forward, natural order in and out, N = 1
 
 constexpr int RT = 256;  // threads of a row-pass workgroup
 
+// A frame whose every sample is one non-zero value (and whose first sample is a number): k_large_decide1 emits Constant
+// from the column tiles' statistics alone (frame/mod.rs:82-88) and nothing ever reads such a frame's rows, norms or
+// polynomial pieces -- a fifth of configs[3]'s series, and the row launch is the large tier's longest.  (A zero
+// extreme or a NaN first sample send the frame to the general kernel, which does read them: no skip.)
+DEVI bool frame_is_constant(const double *xs, const unsigned char *ws, const LargeWs &lay, uint32_t m2)
+{
+    const uint32_t nt = (m2 + FB - 1) / FB;
+    const TileStats *q = (const TileStats *)(ws + lay.o_tst);
+    const double x0 = xs[0];
+    double mn = q[0].mn, mx = q[0].mx;
+    for (uint32_t t = 1; t < nt; ++t) {
+        mn = fmin(mn, q[t].mn);
+        mx = fmax(mx, q[t].mx);
+    }
+    return mn == mx && mn != 0.0 && x0 == x0;
+}
+
 // First trip of the polynomial ladder (polynomial.rs:209-277: points = max(3, n / 100), the plan's pstep[0] / pK[0]) for
 // one piece of 1024 samples, by a 256-thread workgroup -- the arithmetic of k_large_poly1, sample for sample; the
 // piece's share of the MAPE sum and its run starts (rle.rs:142-189) go to the workspace as plain stores.  Runs as extra
@@ -426,11 +443,13 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, Pl);
     if (blockIdx.x >= row_tiles) {  // workgroups behind the row tiles: pieces of the first polynomial trip
         if (f.M2 != 9 * P) return;  // (another launch's frame)
+        if ((sparse_inv & 2) && frame_is_constant(f.xs, f.ws, large_ws_layout(f.n, f.L, Pl->kcap), f.M2)) return;
         poly1_piece(f.xs, *Pl, f.ws, large_ws_layout(f.n, f.L, Pl->kcap), blockIdx.x - row_tiles, (unsigned char *)T);
         return;
     }
     const uint32_t M1 = f.M1, M = f.M;
     if (f.M2 != M2) return;
+    if ((sparse_inv & 2) && frame_is_constant(f.xs, f.ws, large_ws_layout(f.n, f.L, Pl->kcap), f.M2)) return;
     const uint32_t half_pairs = (M1 - 1) / 2;
     const LargeWs lay = large_ws_layout(f.n, f.L, Pl->kcap);
     const float2 *Y = (const float2 *)(f.ws + lay.o_b);
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(RT) void k_large_rows9p(const double *__restrict__ 
         }
         __syncthreads();
         // ---- step 3 ----
-        const bool dense = !(sparse_inv && Pl->sp_mf);
+        const bool dense = !((sparse_inv & 1) && Pl->sp_mf);
         auto finish = [&](uint32_t k, float2 z) {
             spec[k] = z;
             nbits[k] = __float_as_uint((float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y));
@@ -593,6 +612,7 @@ __global__ __launch_bounds__(RT) void k_large_rows_thread(const double *__restri
     const PreFrame f = pre_frame(samples, frames, ids, plans, ws_base, ws_stride, Pl);
     if (f.M2 != M2 || f.M1 != 243 || !f.half) return;
     const LargeWs lay = large_ws_layout(f.n, f.L, Pl->kcap);
+    if ((sparse_inv & 2) && frame_is_constant(f.xs, f.ws, lay, f.M2)) return;
     if (blockIdx.x >= 1) {
         poly1_piece(f.xs, *Pl, f.ws, lay, blockIdx.x - 1, (unsigned char *)T);
         return;
@@ -635,7 +655,7 @@ __global__ __launch_bounds__(RT) void k_large_rows_thread(const double *__restri
     }
     __syncthreads();
     if (!live) return;
-    const bool dense = !(sparse_inv && Pl->sp_mf);
+    const bool dense = !((sparse_inv & 1) && Pl->sp_mf);
     uint32_t zeros = 0;
     auto finish = [&](uint32_t k, float2 v) {
         spec[k] = v;
