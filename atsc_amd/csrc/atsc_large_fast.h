@@ -1339,29 +1339,80 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
             bool bad = r.bad || bd > 3 || groups == 0 || groups > GMAX;
             uint32_t e = 0;
             for (uint32_t gi = 0; gi < (uint32_t)groups && !bad; ++gi) {
-                const double v = rds_value(r, bd);
-                const uint64_t c64 = rds_varint(r);
-                if (r.bad || c64 == 0 || c64 > FAST_RLE_DEC_MAX - e) { bad = true; break; }
-                const uint32_t c = (uint32_t)c64, o = r.pos;
+                // The group's first 64 bytes, one per lane, in ONE read: value, count and -- for a group of up to ~15
+                // starts, i.e. most groups of a gauge -- both marker scans come out of that register by readlane / ballot.
+                // (Field by field through rds_*: five dependent LDS round trips a group, 0.6 us; 41 groups: 24.5 us.)
+                const uint32_t g0 = r.pos;
+                uint32_t c = 0, a = 0, b = 0, o = 0;
+                double v = 0.0;
+                bool fastok = false;
+                {
+                    const uint32_t B = (g0 + lane < r.len) ? (uint32_t)win[g0 + lane] : 0xFFu;  // (255: no marker)
+                    auto rb = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)B, (int)k); };
+                    auto le = [&](uint32_t k, uint32_t nb) -> uint64_t {
+                        uint64_t x = 0;
+                        for (uint32_t q = 0; q < nb; ++q) x |= (uint64_t)rb(k + q) << (8 * q);
+                        return x;
+                    };
+                    auto vint = [&](uint32_t k, uint64_t &val) -> uint32_t {  // width; 0: not a varint
+                        const uint32_t t = rb(k);
+                        if (t < 251) { val = t; return 1; }
+                        if (t == 251) { val = le(k + 1, 2); return 3; }
+                        if (t == 252) { val = le(k + 1, 4); return 5; }
+                        if (t == 253) { val = le(k + 1, 8); return 9; }
+                        return 0;
+                    };
+                    uint64_t raw = 0, c64 = 0;
+                    uint32_t w1;
+                    if (bd == 3) { raw = rb(0); w1 = 1; }
+                    else if (bd == 0) { raw = le(0, 8); w1 = 8; }
+                    else w1 = vint(0, raw);
+                    const uint32_t w2 = w1 ? vint(w1, c64) : 0u;
+                    const uint32_t hh = w1 + w2;  // 2 .. 18
+                    if (w1 && w2 && g0 + hh <= r.len && c64 >= 1 && c64 <= FAST_RLE_DEC_MAX - e) {
+                        c = (uint32_t)c64;
+                        v = bd == 3 ? (double)raw : bd == 2 ? (double)(int16_t)unzig(raw) : bd == 1 ? (double)(int32_t)unzig(raw)
+                                                                                              : __longlong_as_double((long long)raw);
+                        o = g0 + hh;
+                        // (lanes past the window count as "does not conform": the shifts fill with zeros)
+                        const unsigned long long m1 = __ballot(B < 251) >> hh;
+                        a = min((uint32_t)__builtin_ctzll(~m1), c);
+                        if (a == c) {
+                            fastok = true;
+                        } else if (hh + a < 64) {
+                            const uint32_t p3 = hh + a;
+                            const unsigned long long m3 = __ballot(B == 251) >> p3;
+                            const uint32_t k3 = (uint32_t)__builtin_ctzll(~m3 & 0x9249249249249249ull) / 3u;
+                            if (k3 >= c - a) { b = c - a; fastok = true; }
+                            else if (p3 + 3 * k3 < 64) { b = k3; fastok = true; }  // (the marker that ends the scan is in the window)
+                        }
+                    }
+                }
+                if (!fastok) {
+                    v = rds_value(r, bd);
+                    const uint64_t c64 = rds_varint(r);
+                    if (r.bad || c64 == 0 || c64 > FAST_RLE_DEC_MAX - e) { bad = true; break; }
+                    c = (uint32_t)c64; o = r.pos;
+                    // leading 1-byte starts, then 3-byte ones; what is left must be 5-byte starts
+                    a = 0; b = 0;
+                    for (;;) {
+                        const uint32_t k = a + lane;
+                        const bool one = k < c && o + k < r.len && win[o + k] < 251;
+                        const unsigned long long m = __ballot(!one);
+                        if (m) { a += (uint32_t)__builtin_ctzll(m); break; }
+                        a += 64;
+                    }
+                    a = min(a, c);
+                    for (;;) {
+                        const uint32_t k = b + lane;
+                        const bool three = a + k < c && o + a + 3 * k + 2 < r.len && win[o + a + 3 * k] == 251;
+                        const unsigned long long m = __ballot(!three);
+                        if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
+                        b += 64;
+                    }
+                    b = min(b, c - a);
+                }
                 if (lane == 0) gvals[gi] = v;
-                // leading 1-byte starts, then 3-byte ones; what is left must be 5-byte starts
-                uint32_t a = 0, b = 0;
-                for (;;) {
-                    const uint32_t k = a + lane;
-                    const bool one = k < c && o + k < r.len && win[o + k] < 251;
-                    const unsigned long long m = __ballot(!one);
-                    if (m) { a += (uint32_t)__builtin_ctzll(m); break; }
-                    a += 64;
-                }
-                a = min(a, c);
-                for (;;) {
-                    const uint32_t k = b + lane;
-                    const bool three = a + k < c && o + a + 3 * k + 2 < r.len && win[o + a + 3 * k] == 251;
-                    const unsigned long long m = __ballot(!three);
-                    if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
-                    b += 64;
-                }
-                b = min(b, c - a);
                 const uint32_t bytes = a + 3 * b + 5 * (c - a - b);
                 if (o + bytes > r.len) { bad = true; break; }
                 if (lane == 0) gtab[gi] = make_uint4(o, a, b, e);
@@ -1372,6 +1423,7 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
             if (tid == 0) { bc[0] = bad ? 0u : 1u; bc[1] = e; bc[2] = (uint32_t)groups; bc[3] = 0; }
         }
         __syncthreads();
+        DSTAMP(2);
         if (!bc[0] || bc[1] == 0) return;
         {
             const uint32_t E0 = bc[1], D = bc[2];
@@ -1402,34 +1454,82 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
             }
         }
         __syncthreads();
+        DSTAMP(3);
         if (bc[3]) return;
         const uint32_t E = bc[1];
-        uint32_t p2 = 1;
-        while (p2 < E) p2 <<= 1;
-        block_sort<LW, true>((uint64_t *)lk, nullptr, E, p2);
         uint32_t *rstart = (uint32_t *)(ws + lay.o_hp);
         double *rval = (double *)(ws + lay.o_rec);
-        for (uint32_t i = tid; i < E; i += LT) {
-            const unsigned long long k = lk[i];
-            rstart[i] = (uint32_t)(k >> 32);
-            rval[i] = gvals[(uint32_t)(k & 0xffffffffull)];
-        }
         uint32_t *ptab = (uint32_t *)(ws + lay.o_part);
-        if (tid <= geo.tiles) {
-            uint32_t cnt = E;
-            if (tid < geo.tiles) {
-                const uint32_t i0 = (uint32_t)(((uint64_t)fr.n * tid) / geo.tiles);
-                uint32_t lo = 0, hi = E;  // runs with start <= i0
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint32_t)(lk[mid] >> 32) <= i0) lo = mid + 1;
-                    else hi = mid;
-                }
-                cnt = lo;
-            }
-            ptab[tid] = cnt;
+        // A run's place in sample order = the number of runs that start before it.  Starts are distinct unless the stream
+        // holds empty runs, so: one bit per sample where a run starts (16 KB, where the payload and the group table were --
+        // both are done with), the bits counted per 64-sample word and scanned, and every run reads its place off the
+        // counts -- 3 us where sorting the 950 keys of a gauge through 55 barriers took 12.  Two runs on one start: the
+        // sort below.
+        uint32_t *bm = (uint32_t *)(smem + 512);  // n / 32 words (n <= 131072); [smem + 512, zl) is 31232 bytes
+        uint32_t *pre = bm + 4096;                // n / 64 counts, then their exclusive scan
+        const uint32_t nw64 = (fr.n + 63) >> 6;
+        for (uint32_t w = tid; w < 2 * nw64; w += LT) bm[w] = 0;
+        if (tid == 0) bc[4] = 0;
+        __syncthreads();
+        for (uint32_t j = tid; j < E; j += LT) {
+            const uint32_t idx = (uint32_t)(lk[j] >> 32), bit = 1u << (idx & 31u);
+            if (atomicOr(&bm[idx >> 5], bit) & bit) bc[4] = 1;
         }
+        __syncthreads();
+        if (!bc[4]) {
+            for (uint32_t w = tid; w < nw64; w += LT) pre[w] = __popc(bm[2 * w]) + __popc(bm[2 * w + 1]);
+            __syncthreads();
+            (void)block_excl_scan<LW>(pre, nw64, bc + 64);
+            auto upto = [&](uint32_t i) -> uint32_t {  // starts at samples < i
+                const uint32_t w = i >> 6, bi = i & 63u;
+                const unsigned long long word = (unsigned long long)bm[2 * w] | ((unsigned long long)bm[2 * w + 1] << 32);
+                return pre[w] + (uint32_t)__popcll(word & ((1ull << bi) - 1ull));
+            };
+            for (uint32_t j = tid; j < E; j += LT) {
+                const unsigned long long k = lk[j];
+                const uint32_t idx = (uint32_t)(k >> 32), at = upto(idx);
+                rstart[at] = idx;
+                rval[at] = gvals[(uint32_t)(k & 0xffffffffull)];
+            }
+            if (tid <= geo.tiles) {
+                uint32_t cnt = E;
+                if (tid < geo.tiles) {
+                    const uint32_t i0 = (uint32_t)(((uint64_t)fr.n * tid) / geo.tiles);
+                    cnt = upto(i0) + ((bm[i0 >> 5] >> (i0 & 31u)) & 1u);  // runs with start <= i0
+                }
+                ptab[tid] = cnt;
+            }
+        } else {
+            uint32_t p2 = 1;
+            while (p2 < E) p2 <<= 1;
+            block_sort<LW, true>((uint64_t *)lk, nullptr, E, p2);
+            for (uint32_t i = tid; i < E; i += LT) {
+                const unsigned long long k = lk[i];
+                rstart[i] = (uint32_t)(k >> 32);
+                rval[i] = gvals[(uint32_t)(k & 0xffffffffull)];
+            }
+            if (tid <= geo.tiles) {
+                uint32_t cnt = E;
+                if (tid < geo.tiles) {
+                    const uint32_t i0 = (uint32_t)(((uint64_t)fr.n * tid) / geo.tiles);
+                    uint32_t lo = 0, hi = E;  // runs with start <= i0
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint32_t)(lk[mid] >> 32) <= i0) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    cnt = lo;
+                }
+                ptab[tid] = cnt;
+            }
+        }
+        DSTAMP(4);
         if (tid == 0) { fs->K1 = E; fs->status = 4; }
+        DSTAMP(5);
+        if (dbg && tid == 0)
+            printf("DSTAMP dparse RLE: staging %.1f  group walk %.1f  starts %.1f  ranks %.1f  tables %.1f us (%u runs, %u groups)\n",
+                   (double)(dst_[1] - dst_[0]) * 0.01, (double)(dst_[2] - dst_[1]) * 0.01, (double)(dst_[3] - dst_[2]) * 0.01,
+                   (double)(dst_[4] - dst_[3]) * 0.01, (double)(dst_[5] - dst_[4]) * 0.01, E, bc[2]);
         return;
     }
     if (fr.tag == ATSC_POLYNOMIAL) {
@@ -1542,30 +1642,70 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     const uint32_t E = fr.payload_len - hdr - 8;  // bytes of the entries
     if (E < 9 * cnt || E > 11 * cnt || ((11 * cnt - E) & 1u)) return;  // (left to the general decoder, which reports it)
     {
-        uint16_t *Ja = (uint16_t *)zl, *Jb = Ja + STG_BYTES;  // two tables of E + 1 offsets (the list buffers are idle)
-        for (uint32_t o = tid; o <= E; o += LT) {
-            const uint32_t nx = o < E ? o + (win[hdr + o] < 251 ? 9u : 11u) : E;
-            Ja[o] = (uint16_t)min(nx, E);
+        // Where the entries start.  An entry is 9 or 11 bytes, so the chain of starts enters every block of BB bytes
+        // within the block's first 11: thread (block, c) walks the block from its byte c -- 40 dependent byte reads at
+        // most -- and leaves the starts it met, their number and the byte of the next block it came out at; one thread
+        // then follows the real chain from block to block, and every entry is parsed by a thread of its own.  (Before:
+        // next(o) tabulated for every byte offset and squared six times, a hop per 64 entries, the groups of 64 parsed
+        // by a wavefront each in lock step -- 20 us for 1310 entries.)
+        constexpr uint32_t BB = 352, BW = 40, NBMAX = (11 * FAST_K_MAX + BB - 1) / BB;  // 42 blocks of <= 40 entries
+        static_assert(NBMAX * 11 * BW * 2 + NBMAX * 11 * 2 <= 2 * 12 * 2 * FAST_K_MAX, "start tables fit the list buffers");
+        static_assert((NBMAX + 1) * 8 <= 4096, "chain tables fit tab");
+        uint16_t *offs = (uint16_t *)zl;               // [block][c][BW]
+        uint16_t *bxc = offs + NBMAX * 11 * BW;        // [block][c]: count | exit byte << 8 (15: the chain ends inside)
+        uint32_t *centry = tab, *ebase = tab + NBMAX + 1;
+        const uint32_t nblk = (E + BB - 1) / BB;
+        for (uint32_t t = tid; t < nblk * 11; t += LT) {
+            const uint32_t b = t / 11, c = t % 11, bs = b * BB, be = min(bs + BB, E);
+            uint32_t o = bs + c, j = 0;
+            uint16_t *row = offs + t * BW;
+            while (o < be) {  // (j < BW: 352 / 9 < 40)
+                row[j++] = (uint16_t)o;
+                o += win[hdr + o] < 251 ? 9u : 11u;
+            }
+            // out of the last block: exactly at the end of the entries (0), or past it (14: an entry cut short)
+            const uint32_t ex = be == E ? (o == E ? 0u : 14u) : o - be;
+            bxc[t] = (uint16_t)(j | (ex << 8));
         }
         __syncthreads();
-        for (int k = 0; k < 6; ++k) {
-            for (uint32_t o = tid; o <= E; o += LT) Jb[o] = Ja[Ja[o]];
-            __syncthreads();
-            uint16_t *t = Ja; Ja = Jb; Jb = t;
-        }
-        uint32_t *cs = tab;  // group starts (tab is free until the bucketing)
-        const uint32_t ngrp = (cnt + 63) / 64;
         if (tid == 0) {
-            uint32_t o = 0;
-            for (uint32_t k = 0; k < ngrp; ++k) { cs[k] = o; o = Ja[o]; }
-            cs[ngrp] = E;
+            uint32_t c = 0, base = 0;
+            for (uint32_t b = 0; b < nblk; ++b) {
+                centry[b] = c;
+                ebase[b] = base;
+                const uint32_t w = bxc[b * 11 + c];
+                base += w & 0xffu;
+                c = w >> 8;
+            }
+            ebase[nblk] = base;
+            if (c != 0 || base != cnt) bc[3] = 1;  // (left to the general decoder, which reports it)
         }
         __syncthreads();
-        for (uint32_t k = tid >> 6; k < ngrp; k += LW) {
-            RdS r{pay, hdr + E, hdr + cs[k], false, win, 0, hdr + E, STG_BYTES};
-            const uint32_t grp = min(64u, cnt - 64 * k);
-            rds_fft_entries(r, grp, L, ent + 64 * k);
-            if ((r.bad || r.pos != hdr + cs[k + 1]) && (tid & 63) == 0) atomicOr(&bc[3], 1u);
+        if (bc[3]) return;
+        for (uint32_t t = tid; t < nblk * BW; t += LT) {
+            const uint32_t b = t / BW, j = t % BW, row = b * 11 + centry[b];
+            if (j >= (bxc[row] & 0xffu)) continue;
+            const uint32_t o = hdr + offs[row * BW + j], first = win[o];
+            uint32_t pos = first, q = o + 1;
+            if (first == 251) {
+                pos = (uint32_t)win[o + 1] | ((uint32_t)win[o + 2] << 8);
+                q = o + 3;
+            }
+            uint32_t wre = 0, wim = 0;
+            for (uint32_t k = 0; k < 4; ++k) {
+                wre |= (uint32_t)win[q + k] << (8 * k);
+                wim |= (uint32_t)win[q + 4 + k] << (8 * k);
+            }
+            float re = __uint_as_float(wre), im = __uint_as_float(wim);
+            if (first > 251 || pos >= L) {  // (a u16 field: 4- and 8-byte varints cannot occur; rds_fft_entries)
+                bc[3] = 1;
+                continue;
+            }
+            if (pos > L / 2) { pos = L - pos; im = -im; }
+            if (pos == 0 || 2 * pos == L) im = 0.0f;
+            Sel e;
+            e.pos = pos; e.re = re; e.im = im;
+            ent[ebase[b] + j] = e;
         }
         __syncthreads();
         if (bc[3]) return;
@@ -1592,14 +1732,36 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
         lpos[i] = i < cnt ? ent[i].pos : 0xFFFFFFFFu - i;
         ldead[i] = 0;
     }
+    // (a frame with such repeats used to have every entry walk all the entries behind it: 25 us for 1310 of them, one
+    // frame in four at e = 1 %.  The repeats are a handful: the positions found set go to a list, the entries that name a
+    // listed position agree on the last of them by an LDS maximum, and the others are void.)
+    constexpr uint32_t DUPMAX = 64;
+    uint32_t *dupp = tab, *dupl = tab + DUPMAX;  // listed positions, last entry naming each (tab is idle until the bucketing)
     if (tid == 0) bc[4] = 0;
+    if (tid < DUPMAX) dupl[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < cnt; i += LT) {
         const uint32_t p = lpos[i] & 0xffffu, bit = 1u << (p & 31u);
-        if (atomicOr(&bitmap[p >> 5], bit) & bit) bc[4] = 1;  // (positions are < 65536 after the mirroring: L / 2 = 69984)
+        if (atomicOr(&bitmap[p >> 5], bit) & bit) {  // (positions are < 65536: stored as u16, and 65536 < L / 2 = 69984)
+            const uint32_t q = atomicAdd(&bc[4], 1u);
+            if (q < DUPMAX) dupp[q] = lpos[i];
+        }
     }
     __syncthreads();
-    if (bc[4]) {
+    const uint32_t ndup = bc[4];
+    if (ndup && ndup <= DUPMAX) {
+        uint32_t slot[(FAST_K_MAX + LT - 1) / LT];
+        for (uint32_t i = tid, u = 0; i < cnt; i += LT, ++u) {
+            const uint32_t mine = lpos[i];
+            uint32_t q = 0;
+            while (q < ndup && dupp[q] != mine) ++q;
+            slot[u] = q;
+            if (q < ndup) atomicMax(&dupl[q], i);
+        }
+        __syncthreads();
+        for (uint32_t i = tid, u = 0; i < cnt; i += LT, ++u)
+            if (slot[u] < ndup) ldead[i] = i < dupl[slot[u]] ? 1u : 0u;
+    } else if (ndup) {
         for (uint32_t i = tid; i < cnt; i += LT) {
             const uint32_t mine = lpos[i];
             uint32_t dead = 0;

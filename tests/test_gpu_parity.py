@@ -583,6 +583,65 @@ def test_rle_frames_on_the_large_grid_path(ctx, A, oracle, me):
     assert rec == bro[body_off:]
 
 
+def test_hand_built_rle_streams_on_the_large_decoder(ctx, A, oracle):
+    """RLE payloads (rle.rs:204-236) no encoder writes, on the chunker's power-of-two chunks, decoded like the oracle
+    decodes them: two groups naming one start (an empty run: the later group wins -- the grid decoder ranks runs by a
+    bit map of the starts and falls back to its sort when a start repeats), a group's starts in descending order and a
+    small start in the three-byte form (the group walk's marker scans do not apply: the general decoder's), groups
+    of one start and of hundreds, values of every width."""
+    import struct
+    rng = np.random.default_rng(4242)
+
+    def vi(v):
+        return P.H_varint(int(v))
+
+    def val(bd, v):
+        if bd == oracle.BD_U8:
+            return bytes([int(v)])
+        if bd == oracle.BD_F64:
+            return struct.pack("<d", float(v))
+        z = (int(v) << 1) ^ (int(v) >> 63)
+        return vi(z)
+
+    id_byte = oracle.compress(A.RLE, np.repeat([1.0, 2.0], [5, 5]), False, 0.0)[0][:1]
+    recs, want = [], []
+    for n in (8192, 131072):
+        for case in ("empty", "descending", "wide-small", "plain"):
+            for bd, pool in ((oracle.BD_U8, np.arange(0, 200.0)), (oracle.BD_I16, np.arange(-300.0, 300.0, 7)),
+                             (oracle.BD_I32, np.arange(-90000.0, 90000.0, 4001)), (oracle.BD_F64, np.arange(0.5, 90.0, 1.25))):
+                ng = int(rng.integers(2, 40))
+                vals = rng.choice(pool, size=ng, replace=False)
+                nruns = int(rng.integers(ng, 900))
+                starts = np.unique(np.concatenate([[0], rng.integers(1, n, size=nruns - 1),
+                                                   rng.integers(1, 251, size=3), rng.integers(251, min(n, 65536), size=3)]))
+                owner = rng.integers(0, ng, size=len(starts))
+                owner[:ng] = np.arange(ng)  # every group holds a run
+                groups = [sorted(starts[owner == g].tolist()) for g in range(ng)]
+                if case == "empty":  # the later groups repeat some starts of the earlier ones
+                    for g in range(1, ng):
+                        groups[g] = sorted(set(groups[g]) | set(rng.choice(groups[g - 1], size=min(2, len(groups[g - 1])),
+                                                                           replace=False).tolist()))
+                body = b""
+                for g in range(ng):
+                    st = groups[g][::-1] if case == "descending" else groups[g]
+                    body += val(bd, vals[g]) + vi(len(st))
+                    for k, i0 in enumerate(st):
+                        if case == "wide-small" and g == 1 and k == 0 and i0 < 65536:
+                            body += bytes([251]) + struct.pack("<H", i0)
+                        else:
+                            body += vi(i0)
+                pay = id_byte + vi(bd) + vi(ng) + body
+                recs.append(_record(A.RLE, n, pay))
+                want.append(np.array(oracle.decompress(A.RLE, pay, n)))
+    out = ctx.decompress_host(b"".join(recs))
+    ref = np.concatenate(want)
+    assert len(out) == len(ref)
+    pos = 0
+    for k, w in enumerate(want):
+        assert np.array_equal(out[pos:pos + len(w)], w), k
+        pos += len(w)
+
+
 @pytest.mark.parametrize("comp,me", [("FFT", ME5), ("FFT", ME1), ("POLYNOMIAL", ME5), ("POLYNOMIAL", ME1)],
                          ids=["fft-e5", "fft-e1", "poly-e5", "poly-e1"])
 def test_forced_fft_and_polynomial_on_the_large_grid_path(ctx, A, oracle, comp, me):
