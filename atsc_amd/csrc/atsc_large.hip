@@ -2455,15 +2455,23 @@ static hipError_t launch_trip243(uint32_t pmask, uint32_t tiles, uint32_t nb, hi
                                  const uint32_t *ids, const DevPlan *plans, const float2 *twpool, unsigned char *ws,
                                  uint64_t ws_stride, int dbg, double *out)
 {
+    static const char *wm_env = getenv("ATSC_TRIP_WIDE_MAX");  // (A/B aid: tools/trip_width_ab.sh)
+    const uint32_t wide_max = wm_env ? (uint32_t)atoi(wm_env) : (DECODE ? TRIP_WIDE_MAX_DEC : TRIP_WIDE_MAX_ENC);
+#define ATSC_TRIP_T(LG_, TT_)                                                                                                 \
+    {                                                                                                                          \
+        hipError_t e = ensure_dyn_lds((const void *)k_large_trip243<DECODE, FR, LG_, TT_>, FAST_TILE_LDS);                     \
+        if (e != hipSuccess) return e;                                                                                         \
+        hipLaunchKernelGGL((k_large_trip243<DECODE, FR, LG_, TT_>), dim3(gx, nb), dim3(TT_), FAST_TILE_LDS, s, samples, frames, \
+                           ids, plans, twpool, ws, ws_stride, dbg, out);                                                       \
+    }
 #define ATSC_TRIP(LG_)                                                                                                        \
     if (pmask & (1u << LG_)) {                                                                                                 \
-        hipError_t e = ensure_dyn_lds((const void *)k_large_trip243<DECODE, FR, LG_>, FAST_TILE_LDS);                          \
-        if (e != hipSuccess) return e;                                                                                         \
-        hipLaunchKernelGGL((k_large_trip243<DECODE, FR, LG_>), dim3(min(tiles, (9u << LG_) / 16u + (((9u << LG_) & 15u) ? 1u : 0u)), nb), \
-                           dim3(CT), FAST_TILE_LDS, s, samples, frames, ids, plans, twpool, ws, ws_stride, dbg, out);          \
+        const uint32_t gx = min(tiles, (9u << LG_) / 16u + (((9u << LG_) & 15u) ? 1u : 0u));                                    \
+        if (gx * nb <= wide_max) ATSC_TRIP_T(LG_, TRIP_WIDE) else ATSC_TRIP_T(LG_, CT)                                         \
     }
     ATSC_TRIP(5) ATSC_TRIP(4) ATSC_TRIP(3) ATSC_TRIP(2) ATSC_TRIP(1)
 #undef ATSC_TRIP
+#undef ATSC_TRIP_T
     return hipSuccess;
 }
 
@@ -2536,7 +2544,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
     const bool fast = !no_fast && kp.prefft && pre->cols243 && pre->rows9p != 0 && pre->chunks_n && kp.sparse_inv &&
                       kp.bounded && (kp.mode == ATSC_AUTO || kp.mode == ATSC_FFT || kp.mode == ATSC_POLYNOMIAL) && !kp.trial &&
                       kp.trial_res == nullptr && diag == nullptr &&
-                      (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4) && 0.0 <= kp.max_err;
+                      (kp.debug_stop == 0 || kp.debug_stop == -3 || kp.debug_stop == -4 || kp.debug_stop == -6) && 0.0 <= kp.max_err;
     if (fast) {
         e = ensure_dyn_lds(pre->m2_max >= FAST_MD ? (const void *)k_large_decide1_big : (const void *)k_large_decide1,
                            fast_d1_lds(fast_carve(pre->m2_max)));
@@ -2581,7 +2589,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
                 hipLaunchKernelGGL(k_large_decide1, dim3(nb), dim3(LT), fast_d1_lds(cv), s, samples, frames, ids + b0, plans,
                                    twpool, kp, slots, res, ws, ws_stride, cv);
             e = launch_trip243<false, DevFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, samples, frames, ids + b0, plans, twpool,
-                                                ws, ws_stride, kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
+                                                ws, ws_stride, kp.debug_stop == -6 ? 2 : kp.debug_stop <= -3 ? 1 : 0, (double *)nullptr);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_large_decide2, dim3(nb), dim3(LT), FAST_D2_LDS, s, samples, frames, ids + b0, plans, kp,
                                slots, res, ws, ws_stride);

@@ -816,8 +816,21 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // LG: the frame's row dimension is md = 9 . 2^LG (LG = 5: 131072 samples); one instantiation per LG, launched when the
 // batch holds such frames -- the workgroups of a launch leave the frames of another LG alone.  (One kernel with md at run
 // time needs 170 VGPRs where the fixed form needs 161: two wavefronts per SIMD instead of three.)
-template <bool DECODE, class FR, int LG>
-__global__ __launch_bounds__(CT) void k_large_trip243(
+// Threads of a tile's workgroup (TT): the column transforms and the evaluation keep the 192-thread geometry of
+// k_large_cols243 (CT); the bucket sums in front of them -- 20 of a tile's 35 us, a chain of LDS round trips per wavefront
+// -- are dealt over TT / 16 groups of 16 lanes, and the wavefronts past CT end with them.  Two forms: 512 threads for
+// launches that leave the GPU part empty (32 frames of 131072 samples at e = 1 % are 360 working tiles on 256 CUs: a CU that
+// gets two of the 192-thread tiles takes 61 us over them, one that gets one 35 -- 64 -> 45 us for the launch), 192 for
+// launches that fill it.  Where the two cross (tools/trip_width_ab.sh, mixed classes at e = 5 %, us per launch, 192 | 512):
+//   frames      32        64        80        128        256
+//   encoder   52 | 45   74 | 77   75 | 85   115 | 132   196 | 246
+//   decoder   52 | 46   83 | 72   98 | 83   132 | 122   223 | 222
+constexpr int TRIP_WIDE = 512;
+constexpr uint32_t TRIP_WIDE_MAX_ENC = 900, TRIP_WIDE_MAX_DEC = 4096;  // workgroups of a launch up to which the wide form is taken
+__device__ unsigned long long g_trip_log[1024][3];
+__device__ unsigned long long g_trip_span[4] = {~0ull, 0ull, 0ull, 0ull};  // ATSC_DEBUG_STOP=-6: first start, last end, sum, tiles
+template <bool DECODE, class FR, int LG, int TT>
+__global__ __launch_bounds__(TT) void k_large_trip243(
     const double *__restrict__ samples, const FR *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool, unsigned char *__restrict__ ws_base,
     uint64_t ws_stride, int dbg, double *__restrict__ outp)
@@ -841,7 +854,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             double *out = frame_out(outp, fr);
             const uint32_t i0 = (uint32_t)(((uint64_t)n * blockIdx.x) / pieces);
             const uint32_t i1 = (uint32_t)(((uint64_t)n * (blockIdx.x + 1)) / pieces);
-            for (uint32_t j = i0 + tid; j < i1; j += CT) out[j] = v;
+            for (uint32_t j = i0 + tid; j < i1; j += TT) out[j] = v;
             return;
         }
         if (fs->status == 4) {
@@ -861,10 +874,10 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             const uint32_t lane = tid & 63u, wv = tid >> 6;
             if (c0 == 0) {
                 const uint32_t z1 = min(i1, rstart[0]);
-                for (uint32_t j = i0 + tid; j < z1; j += CT) out[j] = 0.0;
+                for (uint32_t j = i0 + tid; j < z1; j += TT) out[j] = 0.0;
             }
             const uint32_t a = c0 ? c0 - 1 : 0;
-            for (uint32_t base = a + 64u * wv; base < c1; base += 64u * (CT / 64)) {
+            for (uint32_t base = a + 64u * wv; base < c1; base += 64u * (TT / 64)) {
                 const uint32_t r = base + lane;
                 uint32_t st = 0, en = 0;
                 double v = 0.0;
@@ -906,7 +919,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             if (sgA > K - 2) sgA = K - 2;
             if (sgB > K - 2) sgB = K - 2;
             if (sgB - sgA + 1 > 1536) return;  // (step >= 16 and pieces of at most 7282 samples: at most 457 segments)
-            for (uint32_t sg = sgA + tid; sg <= sgB; sg += CT) {
+            for (uint32_t sg = sgA + tid; sg <= sgB; sg += TT) {
                 double2 t = make_double2(0.0, 0.0);
                 if (sg >= 1 && sg + 2 < K) {
                     const uint32_t t0i = sg * step;
@@ -920,7 +933,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
                 }
                 mms[sg - sgA] = t;
             }
-            for (uint32_t r = tid; r < step; r += CT) {
+            for (uint32_t r = tid; r < step; r += TT) {
                 const double nt = div_small((double)r, stepd, ry);
                 const double t2 = nt * nt;
                 const double t3 = t2 * nt;
@@ -935,7 +948,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
                 hbt[r] = hh;
             }
             __syncthreads();
-            for (uint32_t i = i0 + tid; i < i1; i += CT) {
+            for (uint32_t i = i0 + tid; i < i1; i += TT) {
                 double sv;
                 if (i == n - 1) {
                     sv = vals[K - 1];
@@ -979,9 +992,9 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     const uint32_t nlist = fs->nlist;
     {
         const uint32_t *gb = (const uint32_t *)(Bb + fast_bounds_off(fs->K1));
-        for (uint32_t e = tid; e < 256; e += CT) { beg[e] = gb[e]; end[e] = gb[256 + e]; border[e] = gb[512 + e]; }
-        for (uint32_t e = tid; e < 243; e += CT) w1[e] = tw[e * (L / FAST_MF)];
-        for (uint32_t e = tid; e < MD; e += CT) wd[e] = tw[e * (L / MD)];
+        for (uint32_t e = tid; e < 256; e += TT) { beg[e] = gb[e]; end[e] = gb[256 + e]; border[e] = gb[512 + e]; }
+        for (uint32_t e = tid; e < 243; e += TT) w1[e] = tw[e * (L / FAST_MF)];
+        for (uint32_t e = tid; e < MD; e += TT) wd[e] = tw[e * (L / MD)];
     }
     const uint32_t c = tid & 15u, q = tid >> 4;
     const uint32_t jb_raw = blockIdx.x * 16 + c;
@@ -998,7 +1011,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     // is what lets four of these workgroups share a CU.  The sum over a bucket runs in list order whichever group it
     // falls to (slots past the bucket's end add zeros).
     {
-        const uint32_t grp = tid >> 4;  // 0 .. 11
+        const uint32_t grp = tid >> 4;  // 0 .. TT / 16 - 1
 
         auto fetch = [&](uint32_t e, uint32_t e1) -> SpEnt {
             SpEnt z;
@@ -1020,15 +1033,18 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
             // where the next batch comes from
             uint32_t ni = i;
             if (last) {
-                ni = i + CT / 16;
+                ni = i + TT / 16;
                 if (ni < FAST_MF) { ka = border[ni]; e = beg[ka]; e1 = end[ka]; twn = tw[jb * ka * P.sc]; }
             } else {
                 e += 16;
             }
             if (ni < FAST_MF) nxt = fetch(e, e1);
-            // (slot U is run while any active row of the wavefront still has an entry there: a uniform branch)
+            // (four slots at a time, run while any row of the wavefront still has an entry among them -- a uniform
+            // branch; a slot past a bucket's end holds a zero entry.  A branch per slot kept the compiler from
+            // requesting a slot's twiddle before the slot in front of it was summed: sixteen LDS round trips a batch
+            // one after the other, 25 of a tile's 44 us.)
 #define ATSC_BKT(U)                                                                                          \
-            if (__ballot(U < cnt)) {                                                                              \
+            {                                                                                                     \
                 const uint32_t ku = dpp_u32<0x150 + U, 0xf>(cur.key);                                             \
                 const float ru = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.re)));                \
                 const float iu = __uint_as_float(dpp_u32<0x150 + U, 0xf>(__float_as_uint(cur.im)));                \
@@ -1036,8 +1052,10 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
                 acc.x += t.x;                                                                                     \
                 acc.y += t.y;                                                                                     \
             }
-            ATSC_BKT(0) ATSC_BKT(1) ATSC_BKT(2) ATSC_BKT(3) ATSC_BKT(4) ATSC_BKT(5) ATSC_BKT(6) ATSC_BKT(7)
-            ATSC_BKT(8) ATSC_BKT(9) ATSC_BKT(10) ATSC_BKT(11) ATSC_BKT(12) ATSC_BKT(13) ATSC_BKT(14) ATSC_BKT(15)
+            if (__ballot(0 < cnt)) { ATSC_BKT(0) ATSC_BKT(1) ATSC_BKT(2) ATSC_BKT(3) }
+            if (__ballot(4 < cnt)) { ATSC_BKT(4) ATSC_BKT(5) ATSC_BKT(6) ATSC_BKT(7) }
+            if (__ballot(8 < cnt)) { ATSC_BKT(8) ATSC_BKT(9) ATSC_BKT(10) ATSC_BKT(11) }
+            if (__ballot(12 < cnt)) { ATSC_BKT(12) ATSC_BKT(13) ATSC_BKT(14) ATSC_BKT(15) }
 #undef ATSC_BKT
             if (last) {
                 T[kc * CSI + c] = cmulc(acc, twc);
@@ -1047,6 +1065,7 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
         }
     }
     __syncthreads();
+    if (tid >= CT) return;  // the wavefronts that only sum buckets are done (a wavefront that has ended does not hold a barrier up)
     TSTAMP(2);
     float2 a[27];
 #pragma unroll
@@ -1151,7 +1170,14 @@ __global__ __launch_bounds__(CT) void k_large_trip243(
     __syncthreads();
     if (tid == 0) ((double *)(ws + lay.o_c + FAST_PARTIAL_OFF))[blockIdx.x] = (red[0] + red[1]) + red[2];
     TSTAMP(4);
-    if (dbg && tid == 0 && blockIdx.x == 3 && blockIdx.y < 5)
+    if (dbg == 2 && tid == 0) {  // span of the launch's working tiles, printed by k_large_decide2
+        atomicMin(&g_trip_span[0], tstamp[0]);
+        atomicMax(&g_trip_span[1], tstamp[4]);
+        atomicAdd(&g_trip_span[2], tstamp[4] - tstamp[0]);
+        const unsigned long long ix = atomicAdd(&g_trip_span[3], 1ull);
+        if (ix < 1024) { g_trip_log[ix][0] = tstamp[0]; g_trip_log[ix][1] = tstamp[4]; g_trip_log[ix][2] = blockIdx.x | (blockIdx.y << 8) | ((unsigned long long)__smid() << 32); }
+    }
+    if (dbg == 1 && tid == 0 && blockIdx.x == 3 && blockIdx.y < 5)
         printf("TSTAMP trip243 frame %u: setup %.1f  bucket sums %.1f  column transform %.1f  evaluation %.1f us (nlist %u)\n", blockIdx.y,
                (double)(tstamp[1] - tstamp[0]) * 0.01, (double)(tstamp[2] - tstamp[1]) * 0.01,
                (double)(tstamp[3] - tstamp[2]) * 0.01, (double)(tstamp[4] - tstamp[3]) * 0.01, nlist);
@@ -1166,6 +1192,15 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
+    if (prm.debug_stop == -6 && blockIdx.x == 0 && tid == 0) {
+        printf("TSPAN trip243: %llu tiles, first start to last end %.1f us, mean tile %.1f us, decide2 starts %.1f us after the last end\n",
+               g_trip_span[3], (double)(g_trip_span[1] - g_trip_span[0]) * 0.01,
+               (double)g_trip_span[2] * 0.01 / (double)max(1ull, g_trip_span[3]), (double)(wall_clock64() - g_trip_span[1]) * 0.01);
+        for (unsigned long long q = 0; q < min(1024ull, g_trip_span[3]); ++q)
+            printf("TLOG %llu %llu %.1f %.1f %llx\n", g_trip_log[q][2] & 255, (g_trip_log[q][2] >> 8) & 0xffffff, (double)(g_trip_log[q][0] - g_trip_span[0]) * 0.01,
+                   (double)(g_trip_log[q][1] - g_trip_span[0]) * 0.01, g_trip_log[q][2] >> 32);
+        g_trip_span[0] = ~0ull; g_trip_span[1] = 0; g_trip_span[2] = 0; g_trip_span[3] = 0;
+    }
     const uint32_t fid = ids[blockIdx.x];
     const DevFrame fr = frames[fid];
     const DevPlan &P = plans[fr.plan];
