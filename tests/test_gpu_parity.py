@@ -1174,6 +1174,41 @@ def test_pipelined_calls_fall_back_to_fewer_chains_when_a_scratch_set_does_not_f
     assert r.returncode == 0 and "FAILSET-OK" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
 
 
+_TRIP_WIDTH_SCRIPT = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import atsc_amd
+from tests import helpers as H
+ctx = atsc_amd.Context(0)
+for me in (float(np.float32(5) / np.float32(100)), float(np.float32(1) / np.float32(100))):
+    for n, nf in ((131072, 40), (32768, 24), (8192, 30)):
+        x = np.concatenate([H.synth_series(640 + k, n, klass=k % 5) for k in range(nf)])
+        off = H.frame_offsets(n * nf, n)
+        rec, _, chosen, err = ctx.compress_host(x, off, atsc_amd.AUTO, True, me, 0)
+        out = ctx.decompress_host(rec)
+        print("TRIPW", n, me, hashlib.sha256(rec).hexdigest(), hashlib.sha256(out.tobytes()).hexdigest(),
+              hashlib.sha256(np.asarray(err).tobytes()).hexdigest())
+"""
+
+
+def test_the_two_tile_widths_of_the_first_fft_trip_agree_bit_for_bit():
+    """k_large_trip243 comes in a 192- and a 512-thread form, picked by the size of the launch (atsc_large_fast.h).  A
+    bucket's sum runs in list order whichever group of 16 lanes it falls to, so the two forms must give the same bits:
+    records, reported errors and decoded samples of the same batches with either form forced (ATSC_TRIP_WIDE_MAX=0 /
+    1000000, read once per process)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for wm in ("0", "1000000"):
+        env = dict(os.environ, ATSC_TRIP_WIDE_MAX=wm)
+        r = subprocess.run([sys.executable, "-c", _TRIP_WIDTH_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("TRIPW")]
+        assert r.returncode == 0 and len(lines) == 6, (r.stdout[-300:], r.stderr[-800:])
+        got.append(lines)
+    assert got[0] == got[1]
+
+
 @pytest.mark.parametrize("F,nf,chains", [(131072, 12, 2), (256, 4096, 4), (131072, 12, 1)])
 def test_pipelined_input_release_lets_the_caller_refill_one_buffer(ctx, A, F, nf, chains):
     """The kernels of a pipelined call read d_samples on the context's streams, not in the caller's stream order
