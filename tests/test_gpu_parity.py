@@ -1611,12 +1611,18 @@ def test_decompress_foreign_fft_streams(ctx, A, oracle):
     rng = np.random.default_rng(77)
     # (513 ... 4096 samples with 16 or more entries: the decoder's inverse transform in LDS, even and odd L; fewer
     # entries, or more than fit beside the spectrum: the direct sum)
-    for n, cnt in ((4097, 700), (8192, 3000), (6561, 60), (20000, 1500), (256, 40), (1000, 300), (100, 30), (40, 12),
-                   (2048, 500), (4096, 1200), (4096, 1700), (3000, 90), (600, 17), (1024, 15), (2048, 16)):
+    # (power-of-two chunks from 8192 samples with at most 1344 entries: the grid decoder -- k_large_dparse's block walks over
+    # entries of both widths, its list of repeated positions (up to 64 of them) and the walk over every later entry
+    # beyond that; positions are u16: below 65536 whatever the transform length)
+    for n, cnt, dups in ((4097, 700, 20), (8192, 3000, 20), (6561, 60, 20), (20000, 1500, 20), (256, 40, 20), (1000, 300, 20),
+                         (100, 30, 20), (40, 12, 20), (2048, 500, 20), (4096, 1200, 20), (4096, 1700, 20), (3000, 90, 20),
+                         (600, 17, 20), (1024, 15, 20), (2048, 16, 20), (131072, 1300, 20), (131072, 1000, 200),
+                         (131072, 1344, 64), (131072, 9, 2), (65536, 600, 70), (32768, 327, 5), (16384, 160, 40), (8192, 81, 3)):
         L = int(oracle.next_size(n)) if n >= 128 else n  # fft.rs:432-444: no padding below 128 samples
-        pos = rng.integers(0, L, size=cnt)
+        pos = rng.integers(0, min(L, 65536), size=cnt)
         pos[: cnt // 3] = rng.integers(0, min(251, L), size=cnt // 3)  # one-byte positions among the wide ones
-        ndup = min(20, cnt // 4)
+        rng.shuffle(pos)
+        ndup = min(dups, cnt // 4)
         pos[cnt // 2: cnt // 2 + ndup] = pos[:ndup]                      # duplicates: the later entry wins
         re = rng.normal(0, 50.0, size=cnt).astype(np.float32)
         im = rng.normal(0, 50.0, size=cnt).astype(np.float32)
