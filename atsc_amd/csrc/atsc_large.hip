@@ -369,7 +369,21 @@ __host__ __device__ inline LargeWs large_ws_layout(uint32_t n, uint32_t L, uint3
     w.bytes = o;
     return w;
 }
-uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap) { return large_ws_layout(n, L, kcap).bytes; }
+// A slot ends with LARGE_WS_TAIL bytes that belong to the LAUNCH, not to the slot's frame (so their place does not depend on
+// the frame's layout): the list of the frames the grid path leaves to the general kernel -- entry i in the tail of slot i,
+// the count behind entry 0 -- see fb_append / k_compress_large.
+constexpr uint64_t LARGE_WS_TAIL = 256;
+constexpr uint32_t FB_GRID_MAX = 256;  // workgroups of the general kernel's launch behind the grid path (one per CU)
+uint64_t large_ws_bytes(uint32_t n, uint32_t L, uint32_t kcap) { return large_ws_layout(n, L, kcap).bytes + LARGE_WS_TAIL; }
+DEVI uint32_t *fb_entry(unsigned char *ws_base, uint64_t ws_stride, uint32_t i)
+{
+    return (uint32_t *)(ws_base + (uint64_t)i * ws_stride + (ws_stride - LARGE_WS_TAIL));
+}
+DEVI uint32_t *fb_count(unsigned char *ws_base, uint64_t ws_stride) { return fb_entry(ws_base, ws_stride, 0) + 1; }
+DEVI void fb_append(unsigned char *ws_base, uint64_t ws_stride, uint32_t slot)  // one thread of the frame's workgroup
+{
+    *fb_entry(ws_base, ws_stride, atomicAdd(fb_count(ws_base, ws_stride), 1u)) = slot;
+}
 
 // exclusive scan over a (global) u32 array by one workgroup; returns the total
 DEVI uint32_t lscan(uint32_t *arr, uint32_t count, uint32_t *wsum)
@@ -1238,10 +1252,10 @@ constexpr uint32_t TRIP_BOUNDS_OFF = 0, TRIP_PARTIAL_OFF = 8192;  // inside buff
 // (k_large_trip_tiles) instead of one after the other on the frame's CU; PART 2 adds the tile sums up and
 // goes on with the ladder.  A frame whose PART 1 never reaches that point is finished there.
 template <int PART>
-__global__ __launch_bounds__(LT) void k_compress_large(
-    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+__device__ __forceinline__ void compress_large_frame(
+    const uint32_t bx, const double *__restrict__ samples, const DevFrame *__restrict__ frames,
     const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
-    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
+    const float2 *__restrict__ twpool, const KParams &prm, uint8_t *__restrict__ slots,
     DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, unsigned char *__restrict__ ws_base,
     uint64_t ws_stride)
 {
@@ -1249,7 +1263,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     constexpr int W = LW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t fid = ids[blockIdx.x];
+    const uint32_t fid = ids[bx];
     const DevFrame fr = frames[fid];
     const DevPlan &P = plans[fr.plan];
     const uint32_t n = P.n, L = P.L, pre = P.pre, bins = P.bins, M = P.M;
@@ -1263,7 +1277,7 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     double4 *hbt = (double4 *)keys;
     int parity = 0;
 
-    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    unsigned char *ws = ws_base + (uint64_t)bx * ws_stride;
     const LargeWs lay = large_ws_layout(n, L, P.kcap);
     float2 *A = (float2 *)(ws + lay.o_a);
     float2 *B = (float2 *)(ws + lay.o_b);
@@ -2386,6 +2400,26 @@ __global__ __launch_bounds__(LT) void k_compress_large(
     LT_STAMP("emitted");
 }
 
+// A workgroup per frame of the launch (slot = blockIdx.x).  Behind the grid path (prm.fast_skip == 2) the launch is as wide
+// as the GPU part at most and its workgroups share out the frames k_large_decide1 / decide2 listed (fb_append): a launch of
+// 1280 workgroups of 1024 threads whose frames are all decided -- the usual case -- took 41 us to start and end them.
+template <int PART>
+__global__ __launch_bounds__(LT) void k_compress_large(
+    const double *__restrict__ samples, const DevFrame *__restrict__ frames,
+    const uint32_t *__restrict__ ids, const DevPlan *__restrict__ plans,
+    const float2 *__restrict__ twpool, const KParams prm, uint8_t *__restrict__ slots,
+    DevResult *__restrict__ res, atsc_frame_diag *__restrict__ diag, unsigned char *__restrict__ ws_base,
+    uint64_t ws_stride)
+{
+    const bool listed = PART == 0 && prm.fast_skip == 2;
+    const uint32_t count = listed ? *fb_count(ws_base, ws_stride) : gridDim.x;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {  // (not listed: one turn, it = blockIdx.x)
+        const uint32_t bx = listed ? *fb_entry(ws_base, ws_stride, it) : it;
+        compress_large_frame<PART>(bx, samples, frames, ids, plans, twpool, prm, slots, res, diag, ws_base, ws_stride);
+        __syncthreads();  // the next frame's first LDS writes stay behind this frame's last reads
+    }
+}
+
 // One tile (SPB output columns) of the first FFT trip of one frame whose k_compress_large<1> stopped at the cut:
 // the tile's share of the MAPE sum goes to the frame's workspace (buffer C, TRIP_PARTIAL_OFF).
 __global__ __launch_bounds__(LT) void k_large_trip_tiles(
@@ -2468,6 +2502,7 @@ static hipError_t launch_trip243(uint32_t pmask, uint32_t tiles, uint32_t nb, hi
     if (pmask & (1u << LG_)) {                                                                                                 \
         const uint32_t gx = min(tiles, (9u << LG_) / 16u + (((9u << LG_) & 15u) ? 1u : 0u));                                    \
         if (gx * nb <= wide_max) ATSC_TRIP_T(LG_, TRIP_WIDE) else ATSC_TRIP_T(LG_, CT)                                         \
+        dbg &= ~4;  /* (the list of the frames left alone is closed by the first launch) */                                    \
     }
     ATSC_TRIP(5) ATSC_TRIP(4) ATSC_TRIP(3) ATSC_TRIP(2) ATSC_TRIP(1)
 #undef ATSC_TRIP
@@ -2552,7 +2587,7 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
         e = ensure_dyn_lds((const void *)k_large_decide2, FAST_D2_LDS);
         if (e != hipSuccess) return e;
         kp.prestats = 1;
-        kp.fast_skip = 1;
+        kp.fast_skip = 2;
     }
     for (uint32_t b0 = 0; b0 < count; b0 += ws_slots) {
         const uint32_t nb = min(ws_slots, count - b0);
@@ -2593,8 +2628,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_large_decide2, dim3(nb), dim3(LT), FAST_D2_LDS, s, samples, frames, ids + b0, plans, kp,
                                slots, res, ws, ws_stride);
-            // whatever those left undecided (FastState::status != 2)
-            hipLaunchKernelGGL(k_compress_large<0>, dim3(nb), dim3(LT), lds, s, samples, frames, ids + b0, plans,
+            // whatever those left undecided (FastState::status != 2: the list k_large_decide2 closed)
+            hipLaunchKernelGGL(k_compress_large<0>, dim3(min(nb, FB_GRID_MAX)), dim3(LT), lds, s, samples, frames, ids + b0, plans,
                                twpool, kp, slots, res, diag, ws, ws_stride);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -2653,8 +2688,8 @@ hipError_t launch_compress_large(uint32_t count, const double *samples, const De
 // (DecPending in the workspace); k_large_pre1 / k_large_pre2 <DevDFrame, true> transform all pending frames
 // over the whole GPU; PH 2 scales, rounds and clamps.
 template <int PH>
-__global__ __launch_bounds__(LT) void k_decompress_large(
-    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+__device__ __forceinline__ void decompress_large_frame(
+    const uint32_t bx, const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
     const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
     const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
     unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse, int sp_split, int fast_skip)
@@ -2662,7 +2697,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     constexpr int T = LT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const DevDFrame fr = frames[ids[blockIdx.x]];
+    const DevDFrame fr = frames[ids[bx]];
     const DevPlan &P = plans[fr.plan];
     const uint32_t n = fr.n, L = P.L, M = P.M, pre = P.pre;
     double *out = outp + fr.out_off;
@@ -2676,7 +2711,7 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     Hdr *hdr = (Hdr *)smem;
     uint32_t *wsum = (uint32_t *)(smem + 64);
 
-    unsigned char *ws = ws_base + (uint64_t)blockIdx.x * ws_stride;
+    unsigned char *ws = ws_base + (uint64_t)bx * ws_stride;
     const LargeWs lay = large_ws_layout(n, L, P.kcap);
     float2 *A = (float2 *)(ws + lay.o_a);
     float2 *Cb = (float2 *)(ws + lay.o_c);
@@ -3106,6 +3141,26 @@ __global__ __launch_bounds__(LT) void k_decompress_large(
     }
 }
 
+// A workgroup per frame of the launch; behind the decoder's grid path with no tile grid of its own to feed (fast_skip == 2)
+// the launch is as wide as the GPU part at most and shares out the frames k_large_dparse left alone (listed by the first
+// k_large_trip243<true> launch), as k_compress_large does.
+template <int PH>
+__global__ __launch_bounds__(LT) void k_decompress_large(
+    const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
+    const DevPlan *__restrict__ plans, const float2 *__restrict__ twpool,
+    const uint8_t *__restrict__ body, double *__restrict__ outp, int *__restrict__ status,
+    unsigned char *__restrict__ ws_base, uint64_t ws_stride, int tiled, int sparse, int sp_split, int fast_skip)
+{
+    const bool listed = PH == 0 && fast_skip == 2;
+    const uint32_t count = listed ? *fb_count(ws_base, ws_stride) : gridDim.x;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {  // (not listed: one turn, it = blockIdx.x)
+        const uint32_t bx = listed ? *fb_entry(ws_base, ws_stride, it) : it;
+        decompress_large_frame<PH>(bx, frames, ids, plans, twpool, body, outp, status, ws_base, ws_stride, tiled, sparse, sp_split,
+                                   fast_skip);
+        __syncthreads();
+    }
+}
+
 // One tile (SPB output columns) of one FFT frame whose list k_decompress_large<0> bucketed (DecPending::pending == 2)
 __global__ __launch_bounds__(LT) void k_decompress_large_tiles(
     const DevDFrame *__restrict__ frames, const uint32_t *__restrict__ ids,
@@ -3210,11 +3265,13 @@ hipError_t launch_decompress_large(uint32_t count, const DevDFrame *frames, cons
                 hipLaunchKernelGGL(k_large_dparse, dim3(nb), dim3(LT), FAST_DP_LDS, s, frames, ids + b0, plans, twpool, body,
                                    ws, ws_stride, dbg);
                 e = launch_trip243<true, DevDFrame>(pre->rows9p, (pre->m2_max + 15) / 16, nb, s, (const double *)nullptr, frames, ids + b0,
-                                                    plans, twpool, ws, ws_stride, 0, out);
+                                                    plans, twpool, ws, ws_stride, 4, out);  // (4: the first launch lists the frames left alone)
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(k_decompress_large<0>, dim3(nb), dim3(LT), lds, s, frames, ids + b0, plans, twpool,
-                               body, out, status, ws, ws_stride, tiled, sparse, sp_split, fast);
+            // (listed: see k_decompress_large; with a tile grid behind it every frame's workgroup has to clear its pending mark)
+            const bool listed = fast && !sp_split;
+            hipLaunchKernelGGL(k_decompress_large<0>, dim3(listed ? min(nb, FB_GRID_MAX) : nb), dim3(LT), lds, s, frames, ids + b0,
+                               plans, twpool, body, out, status, ws, ws_stride, tiled, sparse, sp_split, listed ? 2 : fast);
             if (sp_split)
                 hipLaunchKernelGGL(k_decompress_large_tiles, dim3((nb + 7u) & ~7u, sp_tiles), dim3(LT), SP_LDS_BYTES, s,
                                    frames, ids + b0, plans, twpool, out, ws, ws_stride, nb);

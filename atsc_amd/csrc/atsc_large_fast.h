@@ -272,6 +272,7 @@ __device__ __forceinline__ void large_decide1(
     const LargeWs lay = large_ws_layout(n, L, P.kcap);
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
+    if (blockIdx.x == 0 && tid == 0) *fb_count(ws_base, ws_stride) = 0;  // the launch's list of frames left to the general kernel (k_large_decide2 fills it)
     // why a frame was left to the general kernel (read back under ATSC_DEBUG_STOP=-3 / -4 only)
 #define FAST_WHY(c) do { if (tid == 0) *(uint32_t *)(ws + lay.o_front + 200) = (c); } while (0)
     FAST_WHY(0);
@@ -838,13 +839,17 @@ __global__ __launch_bounds__(TT) void k_large_trip243(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
-#define TSTAMP(i) do { if (dbg) tstamp[i] = wall_clock64(); } while (0)
+#define TSTAMP(i) do { if (dbg & 3) tstamp[i] = wall_clock64(); } while (0)
     TSTAMP(0);
     const FR fr = frames[ids[blockIdx.y]];
     const DevPlan &P = plans[fr.plan];
     unsigned char *ws = ws_base + (uint64_t)blockIdx.y * ws_stride;
     const LargeWs lay = large_ws_layout(P.n, P.L, P.kcap);
     const FastState *fs = (const FastState *)(ws + lay.o_front);
+    if constexpr (DECODE) {
+        // the frames k_large_dparse left alone, listed for k_decompress_large<0> (once: by the first launch, whatever its LG)
+        if ((dbg & 4) && blockIdx.x == 0 && tid == 0 && fs->status == 0) fb_append(ws_base, ws_stride, blockIdx.y);
+    }
     if (fast_geo(P).lg != (uint32_t)LG) return;
     if constexpr (DECODE) {
         if (fs->status == 5) {  // a Constant frame: this workgroup fills piece blockIdx.x
@@ -1215,7 +1220,10 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
         for (uint32_t t = 0; t < tiles; ++t) s += part[t];
         *(double *)(smem + 256) = s;
     }
-    if (fs->status != 1) return;
+    if (fs->status != 1) {  // decided by k_large_decide1 (2), or left by it to the general kernel (0): listed here
+        if (tid == 0 && fs->status == 0) fb_append(ws_base, ws_stride, blockIdx.x);
+        return;
+    }
     const FastState f = *fs;
     uint32_t *wsum = (uint32_t *)smem;
     uint32_t *aux = (uint32_t *)(smem + 512);                       // 2048 u32
@@ -1235,17 +1243,17 @@ __global__ __launch_bounds__(LT) void k_large_decide2(
     if (f.forced) {
         // forced FFT: the first trip ends the ladder (the payload is emitted below, whatever the error) or the general
         // kernel goes on with it
-        if (!fft_ends) { if (tid == 0) fs->status = 0; FAST_WHY(11); return; }
+        if (!fft_ends) { if (tid == 0) { fs->status = 0; fb_append(ws_base, ws_stride, blockIdx.x); } FAST_WHY(11); return; }
         best_size = fft_size; best_owner = 0;
     } else if (fft_ends) {
         if (cur <= me && can_win(fft_size, 0)) { best_size = fft_size; best_owner = 0; }
     } else {
         // the ladder goes on with K2 bins: pruned only if that payload cannot beat a candidate that passes
         const uint32_t K2 = min(P.mf + P.dk1, f.Z);
-        if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) fs->status = 0; FAST_WHY(11); return; }
+        if (K2 <= K1 || can_win(1 + vlen(K2) + 9 * K2 + 8, 0)) { if (tid == 0) { fs->status = 0; fb_append(ws_base, ws_stride, blockIdx.x); } FAST_WHY(11); return; }
     }
-    if (!f.forced && !f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) fs->status = 0; FAST_WHY(12); return; }
-    if (!f.forced && (can_win(f.rle_lb, 2) || best_owner == 3)) { if (tid == 0) fs->status = 0; FAST_WHY(best_owner == 3 ? 14 : 13); return; }
+    if (!f.forced && !f.poly_final && can_win(f.poly2_lb, 1)) { if (tid == 0) { fs->status = 0; fb_append(ws_base, ws_stride, blockIdx.x); } FAST_WHY(12); return; }
+    if (!f.forced && (can_win(f.rle_lb, 2) || best_owner == 3)) { if (tid == 0) { fs->status = 0; fb_append(ws_base, ws_stride, blockIdx.x); } FAST_WHY(best_owner == 3 ? 14 : 13); return; }
     if (best_owner == 1) {
         fast_emit_poly(out, res[fid], xs, n, f.bitdepth, f.poly_K, f.poly_step, f.smin, f.smax, f.poly_err, aux, wsum);
     } else {
@@ -1299,6 +1307,7 @@ __global__ __launch_bounds__(LT) void k_large_dparse(
     const LargeWs lay = large_ws_layout(fr.n, L, P.kcap);
     FastState *fs = (FastState *)(ws + lay.o_front);
     if (tid == 0) fs->status = 0;
+    if (blockIdx.x == 0 && tid == 0) *fb_count(ws_base, ws_stride) = 0;  // (filled by the first k_large_trip243<true> launch)
     const FastGeo geo = fast_geo(P);
     if ((fr.tag != ATSC_FFT && fr.tag != ATSC_POLYNOMIAL && fr.tag != ATSC_RLE && fr.tag != ATSC_CONSTANT) || !geo.ok || (P.pre & 1u) ||
         (fr.n & 1u)) return;
