@@ -1760,6 +1760,39 @@ def test_large_frames_grid_and_single_kernel_forms_agree(ctx, A, monkeypatch):
         assert np.array_equal(out_g, out_1, equal_nan=True)
 
 
+def test_many_frames_left_to_the_general_kernels_are_shared_out(ctx, A, oracle):
+    """Behind the grid paths the general kernels run 256 workgroups at most, which share out the LIST of frames left to
+    them (k_compress_large<0> / k_decompress_large<0>, fb_append): with more listed frames than workgroups a workgroup
+    takes several frames in turn.  Encoder: 640 frames of 8192 samples at e = 0.1 % -- ladders that go on well past
+    their first trip, i.e. left by k_large_decide2 -- forced FFT and auto, against the oracle's encoder.  Decoder: 640 records, Noop frames (left
+    alone by k_large_dparse) between FFT and polynomial ones (taken by it), against the oracle's decode."""
+    n, nf = 8192, 640
+    x = np.concatenate([H.synth_series(7100 + k, n, klass=k % 3) for k in range(nf)])
+    off = H.frame_offsets(n * nf, n)
+    me = float(np.float32(0.1) / np.float32(100))
+    for comp in (A.FFT, A.AUTO):  # (--compressor fft: every ladder runs to its end; auto: the polynomial wins most frames)
+        s = P.compare_batch(oracle, ctx, x, off, comp, True, me)
+        _log(P.assert_summary(s, nf, "640 frames of 8192 samples at e = 0.1 %%, compressor %d, codecs %s" % (comp, s["codecs"])))
+        if comp == A.FFT:
+            ks = [len(H.parse_fft_payload(fr[3])[0]) for fr in H.parse_bro_body(s["records"], with_count=False)]
+            assert sum(1 for k in ks if k > n // 100 + 1) > 300, "the ladders were meant to go on past their first trip"
+    # decoder: the oracle's Noop records of the odd frames between its auto records of the even ones
+    bro_a, _, _ = oracle.stream_compress(x, off, A.AUTO, True, ME5, 0)
+    bro_n, _, _ = oracle.stream_compress(x, off, A.NOOP, False, 0.0, 0)
+    fa = H.parse_bro_body(bytes(bro_a)[A.bro_open(bro_a)[0]:], with_count=False)
+    fn = H.parse_bro_body(bytes(bro_n)[A.bro_open(bro_n)[0]:], with_count=False)
+    recs = b"".join(_record(f[2], f[1], f[3]) for f in (fn[i] if i % 2 else fa[i] for i in range(nf)))
+    ref = np.array(oracle.decompress_data(A.bro_prefix(nf) + recs))
+    out = ctx.decompress_host(recs)
+    for i in range(nf):
+        seg = slice(i * n, (i + 1) * n)
+        if i % 2 == 0 and fa[i][2] == A.FFT:
+            scale = max(np.max(np.abs(ref[seg])), 1e-30)
+            assert np.max(np.abs(out[seg] - ref[seg])) <= (4 + np.log2(n)) * scale * 2.0 ** -23 + 1.00001e-5, i
+        else:
+            assert np.array_equal(out[seg], ref[seg]), (i, fa[i][2])
+
+
 def test_large_fast_path_matches_general_kernel(ctx, A, oracle, monkeypatch):
     """131072-sample frames under the auto selector take the grid path of atsc_large_fast.h (column / row transforms
     in registers, per-frame decisions as their own launches, the tile kernel for the first ladder trip and for the
