@@ -826,7 +826,10 @@ __global__ __launch_bounds__(LT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 //   frames      32        64        80        128        256
 //   encoder   52 | 45   74 | 77   75 | 85   115 | 132   196 | 246
 //   decoder   52 | 46   83 | 72   98 | 83   132 | 122   223 | 222
-constexpr int TRIP_WIDE = 512;
+#ifndef ATSC_TRIP_WIDE
+#define ATSC_TRIP_WIDE 512
+#endif
+constexpr int TRIP_WIDE = ATSC_TRIP_WIDE;
 constexpr uint32_t TRIP_WIDE_MAX_ENC = 900, TRIP_WIDE_MAX_DEC = 4096;  // workgroups of a launch up to which the wide form is taken
 __device__ unsigned long long g_trip_log[1024][3];
 __device__ unsigned long long g_trip_span[4] = {~0ull, 0ull, 0ull, 0ull};  // ATSC_DEBUG_STOP=-6: first start, last end, sum, tiles
